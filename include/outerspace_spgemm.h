@@ -1,0 +1,169 @@
+/*
+ * outerspace_spgemm.h -- C ABI of the MI355X-native outer-product SpGEMM.
+ *
+ * This is the drop-in boundary for the numeric SpGEMM path of anneouyang/OuterSPACE
+ * (all citations relative to the reference's simulator/ directory):
+ *
+ *   reference interface                                         replaced by
+ *   ----------------------------------------------------------  -----------------------------
+ *   CSRMatrix{pos,data{idx,val}}            common.h:10-16,39-47  SoA arrays (ptr/idx/val)
+ *   std::vector<COOMatrix> cscMulcsr(csc, csr)
+ *                                           SimSpGEMM.cpp:265-281  osp_spgemm_csc_csr (multiply)
+ *   COOMatrix deduplicateCOO(coo)           SimSpGEMM.cpp:519-535  osp_spgemm_csc_csr (merge)
+ *   mulflops_ref                            SimSpGEMM.cpp:884-891  osp_result_info.partials
+ *   COOMatrix readcoo(istream&, NRow, NCol, sym)
+ *                                           SimSpGEMM.cpp:55-100   osp_mtx_read
+ *   CSRMatrix coo2csr<transpose>(coo, N)    SimSpGEMM.cpp:102-152  osp_coo_to_compressed_*
+ *   dupcheck -> throw(233)                  SimSpGEMM.cpp:43-53    OSP_ERR_DUPLICATE (= 233)
+ *   assert(csc.pos.size()==csr.pos.size())  SimSpGEMM.cpp:267,882  OSP_ERR_DIM
+ *   main(argv[1]=A.mtx, argv[2]=B.mtx)      SimSpGEMM.cpp:819-894  osp_spgemm_mtx / tools/osp_spgemm
+ *
+ * Conventions: plain pointers and sizes only; no exceptions cross the ABI; every function
+ * returns an osp_status_t (0 = ok); osp_last_error_string() describes the last failure on the
+ * calling thread.  Index type u32 (reference index_t, common.h:7), offsets int64 (reference
+ * size_t), values f32 or f64 (reference value_t is float, common.h:8; f64 is the north-star
+ * target).  Within every compressed segment indices must be strictly ascending (what
+ * coo2csr + dupcheck guarantee in the reference).
+ *
+ * A context owns one GPU, one HIP stream and a buffer pool; it is not thread-safe, use one per
+ * thread.  Results are library-owned handles: query, copy out, destroy.
+ */
+#ifndef OUTERSPACE_SPGEMM_H
+#define OUTERSPACE_SPGEMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSP_VERSION 1
+
+typedef enum osp_status {
+    OSP_OK = 0,
+    OSP_ERR_DIM = 1,         /* inner dimensions differ (reference: assert, SimSpGEMM.cpp:267,882) */
+    OSP_ERR_ARG = 2,         /* null pointer / bad enum / bad size */
+    OSP_ERR_ALLOC = 3,       /* host or device allocation failed */
+    OSP_ERR_HIP = 4,         /* HIP runtime error */
+    OSP_ERR_IO = 5,          /* file could not be read / written */
+    OSP_ERR_RANGE = 6,       /* an index is outside its dimension */
+    OSP_ERR_CAPACITY = 7,    /* one output row's partial products exceed the staging capacity */
+    OSP_ERR_UNSORTED = 8,    /* indices inside a segment are not ascending */
+    OSP_ERR_DUPLICATE = 233  /* duplicate coordinate (reference: throw(233), SimSpGEMM.cpp:49) */
+} osp_status_t;
+
+typedef enum osp_dtype { OSP_F32 = 0, OSP_F64 = 1 } osp_dtype_t;
+typedef enum osp_memspace { OSP_HOST = 0, OSP_DEVICE = 1 } osp_memspace_t;
+
+typedef struct osp_context_s *osp_context_t;
+typedef struct osp_result_s *osp_result_t;
+
+/* Tunables of one multiply.  Zero-initialise, then osp_config_default(). */
+typedef struct osp_config {
+    int validate;               /* 1: check ranges / ordering / duplicates on the device first */
+    uint64_t partial_capacity;  /* max partial products staged in HBM at once (0 = auto);
+                                   the product is processed in output-row panels of at most this */
+    uint64_t k_begin, k_end;    /* restrict the shared dimension to [k_begin,k_end); k_end = 0
+                                   means K.  This is the multi-GPU shard. */
+    int reserved[8];
+} osp_config_t;
+
+/* What one multiply did.  Times are device milliseconds measured with HIP events on the
+ * context's stream. */
+typedef struct osp_result_info {
+    uint64_t M, K, N;
+    uint64_t nnz_a, nnz_b, nnz_c;
+    uint64_t partials;          /* P = sum_k nnz(A[:,k]) * nnz(B[k,:])  (reference mulflops_ref) */
+    uint32_t panels;            /* output-row panels processed */
+    uint64_t light_tiles;       /* merge tiles reduced in LDS */
+    uint64_t heavy_rows;        /* rows reduced by the global-sort path */
+    uint64_t heavy_partials;
+    float ms_symbolic, ms_multiply, ms_merge, ms_compact, ms_total;
+    uint32_t multiply_launches, merge_launches;
+    int dtype;
+} osp_result_info_t;
+
+/* ---- context ------------------------------------------------------------------------- */
+int osp_context_create(int device, osp_context_t *ctx);
+/* Same, but all work is enqueued on an existing hipStream_t (e.g. torch's current stream). */
+int osp_context_create_on_stream(int device, void *hip_stream, osp_context_t *ctx);
+int osp_context_destroy(osp_context_t ctx);
+/* Return pooled device memory to the driver. */
+int osp_context_trim(osp_context_t ctx);
+void osp_config_default(osp_config_t *cfg);
+const char *osp_last_error_string(void);
+const char *osp_status_string(int status);
+
+/* ---- the hot path --------------------------------------------------------------------- */
+/*
+ * C (MxN, CSR) = A (MxK, CSC) * B (KxN, CSR).
+ *   a_colptr[K+1], a_rowidx[nnzA], a_vals[nnzA]   -- reference `csc`  (cscMulcsr arg 1)
+ *   b_rowptr[K+1], b_colidx[nnzB], b_vals[nnzB]   -- reference `csr`  (cscMulcsr arg 2)
+ * `space` says where ALL six input arrays live.  cfg may be NULL (defaults).
+ * Replaces cscMulcsr (SimSpGEMM.cpp:265-281) + deduplicateCOO (:519-535); the result has
+ * ascending column indices per row and keeps entries that cancel to zero, as the reference does.
+ */
+int osp_spgemm_csc_csr(osp_context_t ctx, osp_dtype_t dtype, uint64_t M, uint64_t K, uint64_t N,
+                       const int64_t *a_colptr, const uint32_t *a_rowidx, const void *a_vals,
+                       const int64_t *b_rowptr, const uint32_t *b_colidx, const void *b_vals,
+                       osp_memspace_t space, const osp_config_t *cfg, osp_result_t *result);
+
+/*
+ * Sum `nparts` CSR matrices of identical shape (MxN) into one CSR: the final step of the
+ * k-sharded multi-GPU product after the partial CSRs have been exchanged.
+ * rowptrs[p][M+1], colidxs[p][nnz_p], valss[p][nnz_p]; `space` as above.
+ * Entries are summed in part order (p ascending).
+ */
+int osp_merge_csr_parts(osp_context_t ctx, osp_dtype_t dtype, uint64_t M, uint64_t N, int nparts,
+                        const int64_t *const *rowptrs, const uint32_t *const *colidxs,
+                        const void *const *valss, osp_memspace_t space, const osp_config_t *cfg,
+                        osp_result_t *result);
+
+/* ---- results --------------------------------------------------------------------------- */
+int osp_result_info(osp_result_t r, osp_result_info_t *info);
+/* Copy the CSR out.  rowptr[M+1], colidx[nnz_c], vals[nnz_c]; any pointer may be NULL. */
+int osp_result_copy_csr(osp_result_t r, int64_t *rowptr, uint32_t *colidx, void *vals,
+                        osp_memspace_t space);
+/* Borrow the device arrays (valid until osp_result_destroy). */
+int osp_result_device_ptrs(osp_result_t r, const int64_t **rowptr, const uint32_t **colidx,
+                           const void **vals);
+int osp_result_destroy(osp_result_t r);
+
+/* ---- ingest (host side of the reference CLI) ------------------------------------------ */
+/*
+ * MatrixMarket coordinate reader with the reference's rules (readcoo, SimSpGEMM.cpp:55-100):
+ * lines whose first non-blank character is '%' and blank lines are skipped, the first kept line
+ * is "rows cols nnz", entries are 1-based, a missing value means 1.0, `symmetric` mirrors
+ * off-diagonal entries.  Values come back as parsed doubles.  Arrays are malloc'ed; release
+ * with osp_host_free.
+ */
+int osp_mtx_read(const char *path, int symmetric, uint64_t *nrow, uint64_t *ncol, uint64_t *nnz,
+                 uint32_t **rows, uint32_t **cols, double **vals);
+void osp_host_free(void *p);
+/*
+ * COO -> compressed on the host (coo2csr<transpose>, SimSpGEMM.cpp:102-152): by_col = 0 gives
+ * CSR over `nseg` rows, by_col = 1 gives CSC over `nseg` columns.  Duplicate coordinates return
+ * OSP_ERR_DUPLICATE (233).  Unlike the reference, a matrix with a single non-empty segment is
+ * converted correctly (the reference's back-fill at :143-148 empties it).
+ */
+int osp_coo_to_compressed_f32(int by_col, uint64_t nseg, uint64_t nnz, const uint32_t *rows,
+                              const uint32_t *cols, const float *vals, int64_t *ptr, uint32_t *idx,
+                              float *out_vals);
+int osp_coo_to_compressed_f64(int by_col, uint64_t nseg, uint64_t nnz, const uint32_t *rows,
+                              const uint32_t *cols, const double *vals, int64_t *ptr, uint32_t *idx,
+                              double *out_vals);
+/*
+ * The reference CLI's data flow (main, SimSpGEMM.cpp:819-891) in one call: read both files,
+ * transpose the second operand when transpose_b != 0 (the reference always does, :852-856),
+ * build CSC(A) / CSR(B'), multiply on the GPU.  *partials receives P ("mul flops ref", :891).
+ */
+int osp_spgemm_mtx(osp_context_t ctx, osp_dtype_t dtype, const char *path_a, const char *path_b,
+                   int transpose_b, const osp_config_t *cfg, osp_result_t *result);
+/* Write a CSR result as MatrixMarket "coordinate real general" (1-based, row-major order). */
+int osp_result_write_mtx(osp_result_t r, const char *path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OUTERSPACE_SPGEMM_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of the C ABI declared in ``include/outerspace_spgemm.h``.
+
+The shared library is built in-tree (``outerspace_amd/libouterspace_spgemm.so``) by
+``make -C outerspace_amd/csrc`` / ``__graft_entry__.build()``.  There is no Python or CPU
+fallback: a missing library is an ImportError, a missing GPU is an ``OspError`` at context
+creation.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libouterspace_spgemm.so")
+
+OSP_F32, OSP_F64 = 0, 1
+OSP_HOST, OSP_DEVICE = 0, 1
+OSP_OK = 0
+ERR_DIM, ERR_ARG, ERR_ALLOC, ERR_HIP, ERR_IO, ERR_RANGE, ERR_CAPACITY, ERR_UNSORTED = 1, 2, 3, 4, 5, 6, 7, 8
+ERR_DUPLICATE = 233  # reference: throw(233), simulator/SimSpGEMM.cpp:49
+
+
+class OspError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"[osp status {status}] {message}")
+        self.status = status
+
+
+class Config(C.Structure):
+    _fields_ = [("validate", C.c_int), ("partial_capacity", C.c_uint64), ("k_begin", C.c_uint64),
+                ("k_end", C.c_uint64), ("reserved", C.c_int * 8)]
+
+
+class ResultInfo(C.Structure):
+    _fields_ = [("M", C.c_uint64), ("K", C.c_uint64), ("N", C.c_uint64),
+                ("nnz_a", C.c_uint64), ("nnz_b", C.c_uint64), ("nnz_c", C.c_uint64),
+                ("partials", C.c_uint64), ("panels", C.c_uint32), ("light_tiles", C.c_uint64),
+                ("heavy_rows", C.c_uint64), ("heavy_partials", C.c_uint64),
+                ("ms_symbolic", C.c_float), ("ms_multiply", C.c_float), ("ms_merge", C.c_float),
+                ("ms_compact", C.c_float), ("ms_total", C.c_float),
+                ("multiply_launches", C.c_uint32), ("merge_launches", C.c_uint32), ("dtype", C.c_int)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+# every symbol include/outerspace_spgemm.h declares
+EXPORTS = [
+    "osp_context_create", "osp_context_create_on_stream", "osp_context_destroy", "osp_context_trim",
+    "osp_config_default", "osp_last_error_string", "osp_status_string", "osp_spgemm_csc_csr",
+    "osp_merge_csr_parts", "osp_result_info", "osp_result_copy_csr", "osp_result_device_ptrs",
+    "osp_result_destroy", "osp_mtx_read", "osp_host_free", "osp_coo_to_compressed_f32",
+    "osp_coo_to_compressed_f64", "osp_spgemm_mtx", "osp_result_write_mtx",
+]
+
+_lib = None
+
+
+def lib():
+    """Load the library (once).  Raises ImportError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `make -C outerspace_amd/csrc` "
+                          "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                          "There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    L.osp_last_error_string.restype = C.c_char_p
+    L.osp_status_string.restype = C.c_char_p
+    L.osp_status_string.argtypes = [i32]
+    L.osp_context_create.argtypes = [i32, C.POINTER(vp)]
+    L.osp_context_create_on_stream.argtypes = [i32, vp, C.POINTER(vp)]
+    L.osp_context_destroy.argtypes = [vp]
+    L.osp_context_trim.argtypes = [vp]
+    L.osp_config_default.argtypes = [C.POINTER(Config)]
+    L.osp_config_default.restype = None
+    L.osp_spgemm_csc_csr.argtypes = [vp, i32, u64, u64, u64, vp, vp, vp, vp, vp, vp, i32,
+                                     C.POINTER(Config), C.POINTER(vp)]
+    L.osp_merge_csr_parts.argtypes = [vp, i32, u64, u64, i32, C.POINTER(vp), C.POINTER(vp),
+                                      C.POINTER(vp), i32, C.POINTER(Config), C.POINTER(vp)]
+    L.osp_result_info.argtypes = [vp, C.POINTER(ResultInfo)]
+    L.osp_result_copy_csr.argtypes = [vp, vp, vp, vp, i32]
+    L.osp_result_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.osp_result_destroy.argtypes = [vp]
+    L.osp_mtx_read.argtypes = [C.c_char_p, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64),
+                               C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.osp_host_free.argtypes = [vp]
+    L.osp_host_free.restype = None
+    for sfx in ("f32", "f64"):
+        getattr(L, f"osp_coo_to_compressed_{sfx}").argtypes = [i32, u64, u64, vp, vp, vp, vp, vp, vp]
+    L.osp_spgemm_mtx.argtypes = [vp, i32, C.c_char_p, C.c_char_p, i32, C.POINTER(Config), C.POINTER(vp)]
+    L.osp_result_write_mtx.argtypes = [vp, C.c_char_p]
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != OSP_OK:
+        raise OspError(status, lib().osp_last_error_string().decode(errors="replace"))

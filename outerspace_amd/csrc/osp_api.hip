@@ -1,0 +1,732 @@
+// osp_api.hip -- C ABI (include/outerspace_spgemm.h) and host orchestration of the GPU pipeline.
+//
+// Reference call stack being replaced:
+//   parts = cscMulcsr(csc, csr)      SimSpGEMM.cpp:265-281   -> symbolic + multiply_kernel
+//   C     = deduplicateCOO(concat)   SimSpGEMM.cpp:519-535   -> merge_tiles_kernel / global sort
+// There is no CPU fallback here: every entry point needs a gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/outerspace_spgemm.h"
+#include "osp_internal.h"
+#include "osp_kernels.h"
+
+namespace osp {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return status;
+}
+
+#define OSP_HIP(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            throw Error(e_ == hipErrorOutOfMemory ? OSP_ERR_ALLOC : OSP_ERR_HIP,           \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+// ---- context: device, stream, buffer pool ------------------------------------------------------
+struct Context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::multimap<size_t, void *> free_list;
+    std::map<void *, size_t> live;
+    size_t pooled_bytes = 0;
+
+    static size_t bucket(size_t bytes) {
+        if (bytes < 4096) return 4096;
+        size_t p = 1;
+        while (p * 2 <= bytes) p *= 2;
+        size_t step = p / 8;
+        return (bytes + step - 1) / step * step;
+    }
+    void *alloc(size_t bytes) {
+        size_t b = bucket(bytes ? bytes : 1);
+        auto it = free_list.find(b);
+        void *p = nullptr;
+        if (it != free_list.end()) {
+            p = it->second;
+            free_list.erase(it);
+            pooled_bytes -= b;
+        } else {
+            hipError_t e = hipMalloc(&p, b);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                trim();
+                e = hipMalloc(&p, b);
+            }
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                throw Error(OSP_ERR_ALLOC, "hipMalloc of " + std::to_string(b) + " bytes failed");
+            }
+        }
+        live[p] = b;
+        return p;
+    }
+    void release(void *p) {
+        if (!p) return;
+        auto it = live.find(p);
+        if (it == live.end()) return;
+        free_list.emplace(it->second, p);
+        pooled_bytes += it->second;
+        live.erase(it);
+    }
+    void trim() {
+        for (auto &kv : free_list) (void)hipFree(kv.second);
+        free_list.clear();
+        pooled_bytes = 0;
+    }
+};
+
+// RAII scratch that returns to the pool
+struct Scratch {
+    Context *ctx;
+    std::vector<void *> ptrs;
+    explicit Scratch(Context *c) : ctx(c) {}
+    ~Scratch() { for (void *p : ptrs) ctx->release(p); }
+    template <class T> T *get(uint64_t n) {
+        void *p = ctx->alloc((size_t)(n ? n : 1) * sizeof(T));
+        ptrs.push_back(p);
+        return (T *)p;
+    }
+    void drop(void *p) {
+        for (auto &q : ptrs) if (q == p) { ctx->release(p); q = nullptr; }
+    }
+};
+
+struct Result {
+    Context *ctx = nullptr;
+    int dtype = OSP_F64;
+    osp_result_info_t info{};
+    int64_t *rowptr = nullptr;
+    uint32_t *colidx = nullptr;
+    void *vals = nullptr;
+};
+
+struct PhaseTimer {
+    hipStream_t s;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4];
+    explicit PhaseTimer(hipStream_t st) : s(st) {}
+    ~PhaseTimer() {
+        for (auto &v : ev) for (auto &p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    }
+    void begin(int ph) {
+        hipEvent_t a, b;
+        OSP_HIP(hipEventCreate(&a));
+        OSP_HIP(hipEventCreate(&b));
+        OSP_HIP(hipEventRecord(a, s));
+        ev[ph].push_back({a, b});
+    }
+    void end(int ph) { OSP_HIP(hipEventRecord(ev[ph].back().second, s)); }
+    float total(int ph) {
+        float t = 0;
+        for (auto &p : ev[ph]) { float ms = 0; if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) t += ms; }
+        return t;
+    }
+};
+enum { PH_SYM = 0, PH_MUL = 1, PH_MERGE = 2, PH_COMPACT = 3 };
+
+static inline unsigned grid_for(uint64_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+static inline int bits_for(uint64_t n) {  // bits needed to represent values in [0, n)
+    int b = 0;
+    while (b < 64 && (n > (1ull << b))) b++;
+    return b;
+}
+
+template <class T> static T d2h(const T *dptr, hipStream_t s) {
+    T v;
+    OSP_HIP(hipMemcpyAsync(&v, dptr, sizeof(T), hipMemcpyDeviceToHost, s));
+    OSP_HIP(hipStreamSynchronize(s));
+    return v;
+}
+
+// Where the partial products of a panel come from.
+template <class T> struct Producer {
+    virtual ~Producer() {}
+    // enqueue kernels that fill pcol/pval[0 .. row_off[r1]-row_off[r0]) for rows [r0,r1)
+    virtual void produce(uint64_t r0, uint64_t r1, bool whole, uint64_t base, uint64_t count,
+                         uint32_t *pcol, T *pval) = 0;
+};
+
+// ---- stages shared by both entry points: partial products of each row -> final CSR ----------------
+template <class T>
+static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_t M, uint64_t N,
+                           const uint64_t *d_row_off, uint64_t P, uint64_t cap_cfg, PhaseTimer &tm) {
+    hipStream_t s = ctx->stream;
+    Scratch sc(ctx);
+    constexpr uint32_t kCap = TileCap<T>::value;
+    const int colbits = std::max(1, bits_for(N));
+    const uint32_t max_rows = (uint32_t)std::min<uint64_t>(kTileMaxRows, colbits >= 32 ? 1ull : (1ull << (32 - colbits)));
+
+    res->rowptr = (int64_t *)ctx->alloc((M + 1) * sizeof(int64_t));
+    if (P == 0) {
+        OSP_HIP(hipMemsetAsync(res->rowptr, 0, (M + 1) * sizeof(int64_t), s));
+        res->info.nnz_c = 0;
+        return;
+    }
+    // ---- panels: consecutive rows whose partial products fit the staging capacity --------------
+    size_t free_b = 0, total_b = 0;
+    OSP_HIP(hipMemGetInfo(&free_b, &total_b));
+    free_b += ctx->pooled_bytes;
+    const uint64_t E = 4 + sizeof(T);
+    uint64_t cap = cap_cfg;
+    if (cap == 0) {
+        // staging + merged output + heavy-path scratch must coexist: budget ~30 % of free memory
+        cap = std::max<uint64_t>((uint64_t)(free_b * 0.30 / E), 1ull << 20);
+    }
+    cap = std::min<uint64_t>(cap, 0xfffffff0ull);  // staging positions are u32
+    std::vector<uint64_t> bounds{0};
+    std::vector<uint64_t> h_off;
+    if (P <= cap) {
+        bounds.push_back(M);
+    } else {
+        h_off.resize(M + 1);
+        OSP_HIP(hipMemcpyAsync(h_off.data(), d_row_off, (M + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        OSP_HIP(hipStreamSynchronize(s));
+        uint64_t r = 0;
+        while (r < M) {
+            // largest r1 with row_off[r1] - row_off[r] <= cap
+            uint64_t r1 = std::upper_bound(h_off.begin() + r, h_off.end(), h_off[r] + cap) - h_off.begin() - 1;
+            if (r1 <= r)
+                throw Error(OSP_ERR_CAPACITY, "output row " + std::to_string(r) + " has " +
+                            std::to_string(h_off[r + 1] - h_off[r]) + " partial products, staging capacity is " +
+                            std::to_string(cap));
+            r1 = std::min(r1, M);
+            bounds.push_back(r1);
+            r = r1;
+        }
+    }
+    const uint32_t npanels = (uint32_t)bounds.size() - 1;
+    res->info.panels = npanels;
+    uint64_t max_panel = 0, max_rows_panel = 0;
+    for (uint32_t p = 0; p < npanels; p++) {
+        uint64_t cnt = (npanels == 1) ? P : h_off[bounds[p + 1]] - h_off[bounds[p]];
+        max_panel = std::max(max_panel, cnt);
+        max_rows_panel = std::max(max_rows_panel, bounds[p + 1] - bounds[p]);
+    }
+    uint32_t *pcol = sc.get<uint32_t>(max_panel);
+    T *pval = sc.get<T>(max_panel);
+    uint32_t *row_nnz = sc.get<uint32_t>(M);
+    uint64_t *row_src = sc.get<uint64_t>(M);
+    uint32_t *flag_scan = sc.get<uint32_t>(max_rows_panel + 1);
+    uint32_t *tile_rows = sc.get<uint32_t>(max_rows_panel + 1);
+    uint32_t *heavy_rows = sc.get<uint32_t>(max_rows_panel + 1);
+    uint64_t *c_local = sc.get<uint64_t>(max_rows_panel + 1);
+    uint64_t *scan_tmp = sc.get<uint64_t>(scan_scratch_entries(std::max<uint64_t>(max_rows_panel + 1, 16)));
+
+    struct Piece { uint32_t *col; T *val; uint64_t nnz; };
+    std::vector<Piece> pieces;
+    uint64_t nnz_total = 0;
+
+    for (uint32_t p = 0; p < npanels; p++) {
+        const uint64_t r0 = bounds[p], r1 = bounds[p + 1], nr = r1 - r0;
+        const uint64_t base = (npanels == 1) ? 0 : h_off[r0];
+        const uint64_t count = (npanels == 1) ? P : h_off[r1] - base;
+        // ---- multiply (or scatter of CSR parts) ----
+        tm.begin(PH_MUL);
+        if (count) prod.produce(r0, r1, npanels == 1, base, count, pcol, pval);
+        tm.end(PH_MUL);
+        // ---- merge ----
+        tm.begin(PH_MERGE);
+        TileStartFlag tsf{d_row_off, r0, r1, base, max_rows, kCap / 2};
+        device_exclusive_scan<TileStartFlag, uint32_t>(tsf, nr, flag_scan, (uint32_t *)scan_tmp, s);
+        compact_flagged_kernel<TileStartFlag><<<grid_for(nr, 256), 256, 0, s>>>(tsf, flag_scan, nr, r0, tile_rows);
+        const uint32_t ntiles = d2h(flag_scan + nr, s);
+        HeavyRowFlag hrf{d_row_off, r0, kCap};
+        device_exclusive_scan<HeavyRowFlag, uint32_t>(hrf, nr, flag_scan, (uint32_t *)scan_tmp, s);
+        compact_flagged_kernel<HeavyRowFlag><<<grid_for(nr, 256), 256, 0, s>>>(hrf, flag_scan, nr, r0, heavy_rows);
+        const uint32_t nheavy = d2h(flag_scan + nr, s);
+        if (ntiles) {
+            merge_tiles_kernel<T><<<ntiles, kMergeThreads, 0, s>>>(tile_rows, ntiles, r1, d_row_off, base, colbits,
+                                                                  pcol, pval, row_nnz, row_src);
+            res->info.merge_launches++;
+        }
+        res->info.light_tiles += ntiles - nheavy;
+        if (nheavy) {
+            Scratch hs(ctx);
+            uint64_t *hoff = hs.get<uint64_t>((uint64_t)nheavy + 1);
+            uint64_t *hscan_tmp = hs.get<uint64_t>(scan_scratch_entries(nheavy));
+            device_exclusive_scan<HeavyLen, uint64_t>(HeavyLen{heavy_rows, d_row_off}, nheavy, hoff, hscan_tmp, s);
+            const uint64_t nh = d2h(hoff + nheavy, s);
+            res->info.heavy_rows += nheavy;
+            res->info.heavy_partials += nh;
+            uint64_t *keys[2] = {hs.get<uint64_t>(nh), hs.get<uint64_t>(nh)};
+            uint32_t *poss[2] = {hs.get<uint32_t>(nh), hs.get<uint32_t>(nh)};
+            uint32_t *hist = hs.get<uint32_t>(sort_hist_entries(nh));
+            uint32_t *hist_tmp = hs.get<uint32_t>(scan_scratch_entries(sort_hist_entries(nh)));
+            heavy_fill_kernel<<<grid_for(nh, 256), 256, 0, s>>>(heavy_rows, hoff, nheavy, d_row_off, base, colbits,
+                                                                pcol, nh, keys[0], poss[0]);
+            const int nbits = colbits + bits_for(nheavy);
+            const int cur = device_radix_sort_pairs<uint64_t>(keys, poss, nh, nbits, hist, hist_tmp, s);
+            T *sorted_val = hs.get<T>(nh);
+            heavy_gather_kernel<T><<<grid_for(nh, 256), 256, 0, s>>>(poss[cur], pval, nh, sorted_val);
+            uint64_t *headscan = hs.get<uint64_t>(nh + 1);
+            uint64_t *headscan_tmp = hs.get<uint64_t>(scan_scratch_entries(nh));
+            device_exclusive_scan<HeavyHeadFlag, uint64_t>(HeavyHeadFlag{keys[cur]}, nh, headscan, headscan_tmp, s);
+            heavy_reduce_kernel<T><<<grid_for(nh, 256), 256, 0, s>>>(keys[cur], sorted_val, headscan, nh, heavy_rows,
+                                                                     hoff, nheavy, d_row_off, base, colbits, pcol, pval);
+            heavy_rows_kernel<<<grid_for(nheavy, 256), 256, 0, s>>>(heavy_rows, hoff, nheavy, headscan, d_row_off, base,
+                                                                    row_nnz, row_src);
+            res->info.merge_launches += 4;
+        }
+        tm.end(PH_MERGE);
+        // ---- compaction into the final CSR ----
+        tm.begin(PH_COMPACT);
+        device_exclusive_scan<LoadRowNnz, uint64_t>(LoadRowNnz{row_nnz, r0}, nr, c_local, scan_tmp, s);
+        const uint64_t nnz_panel = d2h(c_local + nr, s);
+        Piece pc{nullptr, nullptr, nnz_panel};
+        pc.col = (uint32_t *)ctx->alloc(std::max<uint64_t>(nnz_panel, 1) * sizeof(uint32_t));
+        pc.val = (T *)ctx->alloc(std::max<uint64_t>(nnz_panel, 1) * sizeof(T));
+        pieces.push_back(pc);
+        if (nnz_panel)
+            compact_rows_kernel<T><<<grid_for((nnz_panel + 7) / 8, 256), 256, 0, s>>>(c_local, r0, nr, row_src, pcol,
+                                                                                     pval, nnz_panel, pc.col, pc.val);
+        rowptr_finalize_kernel<<<grid_for(nr + 1, 256), 256, 0, s>>>(c_local, nr, nnz_total, res->rowptr + r0);
+        nnz_total += nnz_panel;
+        tm.end(PH_COMPACT);
+    }
+    res->info.nnz_c = nnz_total;
+    if (pieces.size() == 1) {
+        res->colidx = pieces[0].col;
+        res->vals = pieces[0].val;
+    } else {
+        OSP_HIP(hipStreamSynchronize(s));
+        sc.drop(pcol);
+        sc.drop(pval);
+        res->colidx = (uint32_t *)ctx->alloc(std::max<uint64_t>(nnz_total, 1) * sizeof(uint32_t));
+        res->vals = ctx->alloc(std::max<uint64_t>(nnz_total, 1) * sizeof(T));
+        uint64_t o = 0;
+        for (auto &pc : pieces) {
+            if (pc.nnz) {
+                OSP_HIP(hipMemcpyAsync(res->colidx + o, pc.col, pc.nnz * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+                OSP_HIP(hipMemcpyAsync((T *)res->vals + o, pc.val, pc.nnz * sizeof(T), hipMemcpyDeviceToDevice, s));
+            }
+            o += pc.nnz;
+        }
+        OSP_HIP(hipStreamSynchronize(s));
+        for (auto &pc : pieces) { ctx->release(pc.col); ctx->release(pc.val); }
+    }
+}
+
+// ---- outer-product producer ---------------------------------------------------------------------
+template <class T> struct OuterProducer : Producer<T> {
+    Context *ctx;
+    Result *res;
+    const int64_t *a_colptr; const uint32_t *a_rowidx; const T *a_vals;
+    const int64_t *b_rowptr; const uint32_t *b_colidx; const T *b_vals;
+    uint64_t k0, k1; int64_t e0;
+    const uint64_t *chunk_off;
+    int64_t *a_start; uint32_t *a_cnt; uint64_t *prod; uint64_t *prod_off; uint64_t *scan_tmp;
+    void produce(uint64_t r0, uint64_t r1, bool whole, uint64_t base, uint64_t count, uint32_t *pcol,
+                 T *pval) override {
+        hipStream_t s = ctx->stream;
+        const uint64_t nk = k1 - k0;
+        panel_columns_kernel<<<grid_for(nk, 256), 256, 0, s>>>(a_colptr, a_rowidx, b_rowptr, k0, nk, (uint32_t)r0, r1,
+                                                               whole ? 1 : 0, a_start, a_cnt, prod);
+        device_exclusive_scan<LoadU64, uint64_t>(LoadU64{prod}, nk, prod_off, scan_tmp, s);
+        const uint64_t nblocks = (count + kMulPerBlock - 1) / kMulPerBlock;
+        multiply_kernel<T><<<(unsigned)nblocks, kMulThreads, 0, s>>>(a_vals, b_colidx, b_vals, b_rowptr, chunk_off, e0,
+                                                                     a_start, a_cnt, prod_off, k0, nk, count, base, pcol,
+                                                                     pval);
+        res->info.multiply_launches++;
+    }
+};
+
+template <class T> struct PartsProducer : Producer<T> {
+    Context *ctx;
+    const int64_t *const *d_rowptrs; const uint32_t *const *d_colidxs; const T *const *d_valss;
+    int nparts;
+    const uint64_t *row_off;
+    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, uint32_t *pcol, T *pval) override {
+        const uint64_t nr = r1 - r0;
+        parts_scatter_kernel<T><<<grid_for(nr * kWave, 256), 256, 0, ctx->stream>>>(d_rowptrs, d_colidxs, d_valss, nparts,
+                                                                                    r0, r1, row_off, base, pcol, pval);
+    }
+};
+
+// Copies an input array to the device when it lives on the host.
+template <class T>
+static const T *to_device(Scratch &sc, const T *p, uint64_t n, osp_memspace_t space, hipStream_t s) {
+    if (space == OSP_DEVICE || n == 0) return p;
+    T *d = sc.get<T>(n);
+    OSP_HIP(hipMemcpyAsync(d, p, n * sizeof(T), hipMemcpyHostToDevice, s));
+    return d;
+}
+
+static void check_flags(uint32_t f, const char *what) {
+    if (f & kFlagPtr) throw Error(OSP_ERR_ARG, std::string(what) + ": pointer array is not a monotone 0..nnz sequence");
+    if (f & kFlagRange) throw Error(OSP_ERR_RANGE, std::string(what) + ": index outside its dimension");
+    if (f & kFlagDuplicate) throw Error(OSP_ERR_DUPLICATE, std::string(what) + ": duplicate coordinate (reference: throw(233))");
+    if (f & kFlagUnsorted) throw Error(OSP_ERR_UNSORTED, std::string(what) + ": indices inside a segment are not ascending");
+}
+
+template <class T>
+static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint64_t N, const int64_t *a_colptr_in,
+                        const uint32_t *a_rowidx_in, const T *a_vals_in, const int64_t *b_rowptr_in,
+                        const uint32_t *b_colidx_in, const T *b_vals_in, osp_memspace_t space,
+                        const osp_config_t &cfg) {
+    hipStream_t s = ctx->stream;
+    Scratch sc(ctx);
+    PhaseTimer tm(s);
+    hipEvent_t ev0, ev1;
+    OSP_HIP(hipEventCreate(&ev0));
+    OSP_HIP(hipEventCreate(&ev1));
+    OSP_HIP(hipEventRecord(ev0, s));
+
+    // pointer arrays first: nnz comes from their last entries
+    const int64_t *a_colptr = to_device(sc, a_colptr_in, K + 1, space, s);
+    const int64_t *b_rowptr = to_device(sc, b_rowptr_in, K + 1, space, s);
+    int64_t nnz_a, nnz_b;
+    if (space == OSP_HOST) { nnz_a = a_colptr_in[K]; nnz_b = b_rowptr_in[K]; }
+    else { nnz_a = d2h(a_colptr + K, s); nnz_b = d2h(b_rowptr + K, s); }
+    if (nnz_a < 0 || nnz_b < 0) throw Error(OSP_ERR_ARG, "negative nnz in pointer array");
+    if ((uint64_t)nnz_a >= 0xffffffffull || (uint64_t)nnz_b >= 0xffffffffull)
+        throw Error(OSP_ERR_ARG, "operands with >= 2^32 non-zeros are not supported");
+    const uint32_t *a_rowidx = to_device(sc, a_rowidx_in, nnz_a, space, s);
+    const T *a_vals = to_device(sc, a_vals_in, nnz_a, space, s);
+    const uint32_t *b_colidx = to_device(sc, b_colidx_in, nnz_b, space, s);
+    const T *b_vals = to_device(sc, b_vals_in, nnz_b, space, s);
+    res->info.nnz_a = nnz_a;
+    res->info.nnz_b = nnz_b;
+
+    if (cfg.validate) {
+        uint32_t *flags = sc.get<uint32_t>(2);
+        OSP_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(uint32_t), s));
+        validate_ptr_kernel<<<grid_for(K + 1, 256), 256, 0, s>>>(a_colptr, K, nnz_a, flags);
+        validate_ptr_kernel<<<grid_for(K + 1, 256), 256, 0, s>>>(b_rowptr, K, nnz_b, flags + 1);
+        check_flags(d2h(flags, s), "A (CSC)");
+        check_flags(d2h(flags + 1, s), "B (CSR)");
+        if (nnz_a) validate_idx_kernel<<<grid_for(nnz_a, 256), 256, 0, s>>>(a_colptr, a_rowidx, K, nnz_a, M, flags);
+        if (nnz_b) validate_idx_kernel<<<grid_for(nnz_b, 256), 256, 0, s>>>(b_rowptr, b_colidx, K, nnz_b, N, flags + 1);
+        check_flags(d2h(flags, s), "A (CSC)");
+        check_flags(d2h(flags + 1, s), "B (CSR)");
+    }
+
+    // ---- k shard ----
+    const uint64_t k0 = cfg.k_begin, k1 = cfg.k_end ? cfg.k_end : K;
+    if (k0 > k1 || k1 > K) throw Error(OSP_ERR_ARG, "k range outside [0,K]");
+    int64_t e0 = 0, e1 = nnz_a;
+    if (k0 != 0 || k1 != K) {
+        if (space == OSP_HOST) { e0 = a_colptr_in[k0]; e1 = a_colptr_in[k1]; }
+        else { e0 = d2h(a_colptr + k0, s); e1 = d2h(a_colptr + k1, s); }
+    }
+    const uint64_t nnz = (uint64_t)(e1 - e0);  // non-zeros of A inside the shard
+
+    // ---- symbolic: chunk offsets in (row, k) order ----
+    tm.begin(PH_SYM);
+    uint64_t *row_off = sc.get<uint64_t>(M + 1);
+    uint64_t *chunk_off = sc.get<uint64_t>(nnz);
+    uint64_t P = 0;
+    if (nnz == 0) {
+        OSP_HIP(hipMemsetAsync(row_off, 0, (M + 1) * sizeof(uint64_t), s));
+    } else {
+        Scratch ss(ctx);
+        uint32_t *keys[2] = {ss.get<uint32_t>(nnz), ss.get<uint32_t>(nnz)};
+        uint32_t *perm[2] = {ss.get<uint32_t>(nnz), ss.get<uint32_t>(nnz)};
+        uint32_t *w = ss.get<uint32_t>(nnz);
+        uint32_t *hist = ss.get<uint32_t>(sort_hist_entries(nnz));
+        uint32_t *hist_tmp = ss.get<uint32_t>(scan_scratch_entries(sort_hist_entries(nnz)));
+        uint64_t *offs_sorted = ss.get<uint64_t>(nnz + 1);
+        uint64_t *scan_tmp = ss.get<uint64_t>(scan_scratch_entries(nnz));
+        sym_expand_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(a_colptr, a_rowidx, b_rowptr, k0, k1, e0, nnz, keys[0],
+                                                             perm[0], w);
+        const int cur = device_radix_sort_pairs<uint32_t>(keys, perm, nnz, std::max(1, bits_for(M)), hist, hist_tmp, s);
+        device_exclusive_scan<LoadGatherW, uint64_t>(LoadGatherW{w, perm[cur]}, nnz, offs_sorted, scan_tmp, s);
+        sym_scatter_offsets_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(perm[cur], offs_sorted, nnz, chunk_off);
+        sym_row_offsets_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(keys[cur], offs_sorted, nnz, M, row_off);
+        P = d2h(offs_sorted + nnz, s);
+    }
+    tm.end(PH_SYM);
+    res->info.partials = P;
+
+    OuterProducer<T> prod;
+    prod.ctx = ctx; prod.res = res;
+    prod.a_colptr = a_colptr; prod.a_rowidx = a_rowidx; prod.a_vals = a_vals;
+    prod.b_rowptr = b_rowptr; prod.b_colidx = b_colidx; prod.b_vals = b_vals;
+    prod.k0 = k0; prod.k1 = k1; prod.e0 = e0; prod.chunk_off = chunk_off;
+    const uint64_t nk = k1 - k0;
+    prod.a_start = sc.get<int64_t>(nk); prod.a_cnt = sc.get<uint32_t>(nk);
+    prod.prod = sc.get<uint64_t>(nk); prod.prod_off = sc.get<uint64_t>(nk + 1);
+    prod.scan_tmp = sc.get<uint64_t>(scan_scratch_entries(nk));
+
+    merge_pipeline<T>(ctx, res, prod, M, N, row_off, P, cfg.partial_capacity, tm);
+
+    OSP_HIP(hipEventRecord(ev1, s));
+    OSP_HIP(hipStreamSynchronize(s));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    res->info.ms_total = ms;
+    res->info.ms_symbolic = tm.total(PH_SYM);
+    res->info.ms_multiply = tm.total(PH_MUL);
+    res->info.ms_merge = tm.total(PH_MERGE);
+    res->info.ms_compact = tm.total(PH_COMPACT);
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+}
+
+template <class T>
+static void merge_parts_impl(Context *ctx, Result *res, uint64_t M, uint64_t N, int nparts,
+                             const int64_t *const *rowptrs, const uint32_t *const *colidxs, const void *const *valss,
+                             osp_memspace_t space, const osp_config_t &cfg) {
+    hipStream_t s = ctx->stream;
+    Scratch sc(ctx);
+    PhaseTimer tm(s);
+    hipEvent_t ev0, ev1;
+    OSP_HIP(hipEventCreate(&ev0));
+    OSP_HIP(hipEventCreate(&ev1));
+    OSP_HIP(hipEventRecord(ev0, s));
+    std::vector<const int64_t *> rp(nparts);
+    std::vector<const uint32_t *> ci(nparts);
+    std::vector<const T *> va(nparts);
+    uint64_t nnz_in = 0;
+    for (int p = 0; p < nparts; p++) {
+        rp[p] = to_device(sc, rowptrs[p], M + 1, space, s);
+        int64_t nnz = (space == OSP_HOST) ? rowptrs[p][M] : d2h(rp[p] + M, s);
+        if (nnz < 0) throw Error(OSP_ERR_ARG, "negative nnz in part");
+        ci[p] = to_device(sc, colidxs[p], nnz, space, s);
+        va[p] = to_device(sc, (const T *)valss[p], nnz, space, s);
+        nnz_in += nnz;
+    }
+    res->info.nnz_a = nnz_in;
+    const int64_t **d_rp = (const int64_t **)sc.get<void *>(nparts);
+    const uint32_t **d_ci = (const uint32_t **)sc.get<void *>(nparts);
+    const T **d_va = (const T **)sc.get<void *>(nparts);
+    OSP_HIP(hipMemcpyAsync(d_rp, rp.data(), nparts * sizeof(void *), hipMemcpyHostToDevice, s));
+    OSP_HIP(hipMemcpyAsync(d_ci, ci.data(), nparts * sizeof(void *), hipMemcpyHostToDevice, s));
+    OSP_HIP(hipMemcpyAsync(d_va, va.data(), nparts * sizeof(void *), hipMemcpyHostToDevice, s));
+    tm.begin(PH_SYM);
+    uint64_t *row_off = sc.get<uint64_t>(M + 1);
+    uint64_t *scan_tmp = sc.get<uint64_t>(scan_scratch_entries(M));
+    device_exclusive_scan<PartsRowLen, uint64_t>(PartsRowLen{d_rp, nparts}, M, row_off, scan_tmp, s);
+    const uint64_t P = d2h(row_off + M, s);
+    tm.end(PH_SYM);
+    res->info.partials = P;
+    PartsProducer<T> prod;
+    prod.ctx = ctx; prod.d_rowptrs = d_rp; prod.d_colidxs = d_ci; prod.d_valss = d_va;
+    prod.nparts = nparts; prod.row_off = row_off;
+    merge_pipeline<T>(ctx, res, prod, M, N, row_off, P, cfg.partial_capacity, tm);
+    OSP_HIP(hipEventRecord(ev1, s));
+    OSP_HIP(hipStreamSynchronize(s));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    res->info.ms_total = ms;
+    res->info.ms_symbolic = tm.total(PH_SYM);
+    res->info.ms_multiply = tm.total(PH_MUL);
+    res->info.ms_merge = tm.total(PH_MERGE);
+    res->info.ms_compact = tm.total(PH_COMPACT);
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+}
+
+static void destroy_result(Result *r) {
+    if (!r) return;
+    if (r->ctx) {
+        r->ctx->release(r->rowptr);
+        r->ctx->release(r->colidx);
+        r->ctx->release(r->vals);
+    }
+    delete r;
+}
+
+}  // namespace osp
+
+using namespace osp;
+
+// ---- C ABI ---------------------------------------------------------------------------------------
+#define OSP_GUARD_BEGIN try {
+#define OSP_GUARD_END                                                 \
+    }                                                                 \
+    catch (const Error &e) { return fail(e.status, "%s", e.what()); } \
+    catch (const std::bad_alloc &) { return fail(OSP_ERR_ALLOC, "host allocation failed"); } \
+    catch (const std::exception &e) { return fail(OSP_ERR_HIP, "%s", e.what()); }
+
+extern "C" {
+
+const char *osp_last_error_string(void) { return g_last_error.c_str(); }
+
+const char *osp_status_string(int st) {
+    switch (st) {
+        case OSP_OK: return "ok";
+        case OSP_ERR_DIM: return "inner dimensions differ";
+        case OSP_ERR_ARG: return "bad argument";
+        case OSP_ERR_ALLOC: return "allocation failed";
+        case OSP_ERR_HIP: return "HIP error";
+        case OSP_ERR_IO: return "I/O error";
+        case OSP_ERR_RANGE: return "index out of range";
+        case OSP_ERR_CAPACITY: return "staging capacity exceeded";
+        case OSP_ERR_UNSORTED: return "indices not ascending";
+        case OSP_ERR_DUPLICATE: return "duplicate coordinate (233)";
+        default: return "unknown status";
+    }
+}
+
+void osp_config_default(osp_config_t *cfg) {
+    if (!cfg) return;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->validate = 1;
+}
+
+static int context_create(int device, void *stream, bool own, osp_context_t *out) {
+    if (!out) return fail(OSP_ERR_ARG, "null context pointer");
+    OSP_GUARD_BEGIN
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        throw Error(OSP_ERR_HIP, "no HIP device visible: this library has no CPU path");
+    if (device < 0 || device >= ndev) throw Error(OSP_ERR_ARG, "device ordinal out of range");
+    OSP_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    OSP_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        throw Error(OSP_ERR_HIP, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    Context *c = new Context;
+    c->device = device;
+    if (own) { OSP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    else c->stream = (hipStream_t)stream;
+    *out = (osp_context_t)c;
+    return OSP_OK;
+    OSP_GUARD_END
+}
+int osp_context_create(int device, osp_context_t *ctx) { return context_create(device, nullptr, true, ctx); }
+int osp_context_create_on_stream(int device, void *hip_stream, osp_context_t *ctx) {
+    return context_create(device, hip_stream, false, ctx);
+}
+int osp_context_trim(osp_context_t c) {
+    if (!c) return fail(OSP_ERR_ARG, "null context");
+    ((Context *)c)->trim();
+    return OSP_OK;
+}
+int osp_context_destroy(osp_context_t c_) {
+    Context *c = (Context *)c_;
+    if (!c) return OSP_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->trim();
+    for (auto &kv : c->live) (void)hipFree(kv.first);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return OSP_OK;
+}
+
+int osp_spgemm_csc_csr(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, uint64_t K, uint64_t N,
+                       const int64_t *a_colptr, const uint32_t *a_rowidx, const void *a_vals,
+                       const int64_t *b_rowptr, const uint32_t *b_colidx, const void *b_vals,
+                       osp_memspace_t space, const osp_config_t *cfg_, osp_result_t *result) {
+    Context *ctx = (Context *)ctx_;
+    if (!ctx || !result) return fail(OSP_ERR_ARG, "null context or result pointer");
+    if (!a_colptr || !b_rowptr) return fail(OSP_ERR_ARG, "null pointer array");
+    if (dtype != OSP_F32 && dtype != OSP_F64) return fail(OSP_ERR_ARG, "dtype must be OSP_F32 or OSP_F64");
+    if (space != OSP_HOST && space != OSP_DEVICE) return fail(OSP_ERR_ARG, "bad memory space");
+    if (M >= 0xffffffffull || N > 0xffffffffull || K >= 0xffffffffull) return fail(OSP_ERR_ARG, "dimension exceeds the u32 index type");
+    osp_config_t cfg;
+    if (cfg_) cfg = *cfg_; else osp_config_default(&cfg);
+    Result *res = new Result;
+    res->ctx = ctx;
+    res->dtype = dtype;
+    res->info.M = M; res->info.K = K; res->info.N = N; res->info.dtype = dtype;
+    try {
+        OSP_HIP(hipSetDevice(ctx->device));
+        if (dtype == OSP_F32)
+            spgemm_impl<float>(ctx, res, M, K, N, a_colptr, a_rowidx, (const float *)a_vals, b_rowptr, b_colidx,
+                               (const float *)b_vals, space, cfg);
+        else
+            spgemm_impl<double>(ctx, res, M, K, N, a_colptr, a_rowidx, (const double *)a_vals, b_rowptr, b_colidx,
+                                (const double *)b_vals, space, cfg);
+    } catch (const Error &e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        destroy_result(res);
+        return fail(e.status, "%s", e.what());
+    } catch (const std::exception &e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        destroy_result(res);
+        return fail(OSP_ERR_ALLOC, "%s", e.what());
+    }
+    *result = (osp_result_t)res;
+    return OSP_OK;
+}
+
+int osp_merge_csr_parts(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, uint64_t N, int nparts,
+                        const int64_t *const *rowptrs, const uint32_t *const *colidxs,
+                        const void *const *valss, osp_memspace_t space, const osp_config_t *cfg_,
+                        osp_result_t *result) {
+    Context *ctx = (Context *)ctx_;
+    if (!ctx || !result || !rowptrs || !colidxs || !valss) return fail(OSP_ERR_ARG, "null argument");
+    if (nparts < 1) return fail(OSP_ERR_ARG, "nparts must be >= 1");
+    if (dtype != OSP_F32 && dtype != OSP_F64) return fail(OSP_ERR_ARG, "dtype must be OSP_F32 or OSP_F64");
+    if (M >= 0xffffffffull || N > 0xffffffffull) return fail(OSP_ERR_ARG, "dimension exceeds the u32 index type");
+    osp_config_t cfg;
+    if (cfg_) cfg = *cfg_; else osp_config_default(&cfg);
+    Result *res = new Result;
+    res->ctx = ctx;
+    res->dtype = dtype;
+    res->info.M = M; res->info.N = N; res->info.dtype = dtype;
+    try {
+        OSP_HIP(hipSetDevice(ctx->device));
+        if (dtype == OSP_F32) merge_parts_impl<float>(ctx, res, M, N, nparts, rowptrs, colidxs, valss, space, cfg);
+        else merge_parts_impl<double>(ctx, res, M, N, nparts, rowptrs, colidxs, valss, space, cfg);
+    } catch (const Error &e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        destroy_result(res);
+        return fail(e.status, "%s", e.what());
+    } catch (const std::exception &e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        destroy_result(res);
+        return fail(OSP_ERR_ALLOC, "%s", e.what());
+    }
+    *result = (osp_result_t)res;
+    return OSP_OK;
+}
+
+int osp_result_info(osp_result_t r_, osp_result_info_t *info) {
+    Result *r = (Result *)r_;
+    if (!r || !info) return fail(OSP_ERR_ARG, "null argument");
+    *info = r->info;
+    return OSP_OK;
+}
+
+int osp_result_copy_csr(osp_result_t r_, int64_t *rowptr, uint32_t *colidx, void *vals, osp_memspace_t space) {
+    Result *r = (Result *)r_;
+    if (!r) return fail(OSP_ERR_ARG, "null result");
+    OSP_GUARD_BEGIN
+    OSP_HIP(hipSetDevice(r->ctx->device));
+    hipStream_t s = r->ctx->stream;
+    const hipMemcpyKind kind = space == OSP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    const size_t vs = r->dtype == OSP_F32 ? 4 : 8;
+    if (rowptr) OSP_HIP(hipMemcpyAsync(rowptr, r->rowptr, (r->info.M + 1) * sizeof(int64_t), kind, s));
+    if (colidx && r->info.nnz_c) OSP_HIP(hipMemcpyAsync(colidx, r->colidx, r->info.nnz_c * sizeof(uint32_t), kind, s));
+    if (vals && r->info.nnz_c) OSP_HIP(hipMemcpyAsync(vals, r->vals, r->info.nnz_c * vs, kind, s));
+    OSP_HIP(hipStreamSynchronize(s));
+    return OSP_OK;
+    OSP_GUARD_END
+}
+
+int osp_result_device_ptrs(osp_result_t r_, const int64_t **rowptr, const uint32_t **colidx, const void **vals) {
+    Result *r = (Result *)r_;
+    if (!r) return fail(OSP_ERR_ARG, "null result");
+    if (rowptr) *rowptr = r->rowptr;
+    if (colidx) *colidx = r->colidx;
+    if (vals) *vals = r->vals;
+    return OSP_OK;
+}
+
+int osp_result_destroy(osp_result_t r_) {
+    destroy_result((Result *)r_);
+    return OSP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,217 @@
+// osp_host.cpp -- host side of the reference CLI's data flow (no GPU code):
+//   osp_mtx_read               readcoo                    SimSpGEMM.cpp:55-100
+//   osp_coo_to_compressed_*    coo2csr<transpose>+dupcheck SimSpGEMM.cpp:102-152, 43-53
+//   osp_spgemm_mtx             main()                      SimSpGEMM.cpp:819-891
+//   osp_result_write_mtx       the format util.py:61-62 (scipy.io.mmwrite) produces
+#include <algorithm>
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "../../include/outerspace_spgemm.h"
+#include "osp_internal.h"
+
+using osp::fail;
+
+extern "C" {
+
+void osp_host_free(void *p) { free(p); }
+
+int osp_mtx_read(const char *path, int symmetric, uint64_t *nrow, uint64_t *ncol, uint64_t *nnz,
+                 uint32_t **rows, uint32_t **cols, double **vals) {
+    if (!path || !nrow || !ncol || !nnz || !rows || !cols || !vals) return fail(OSP_ERR_ARG, "null argument");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(OSP_ERR_IO, "cannot open %s", path);
+    std::vector<uint32_t> r, c;
+    std::vector<double> v;
+    char *line = nullptr;
+    size_t cap = 0;
+    bool header = true;
+    unsigned long long NR = 0, NC = 0, NZ = 0;
+    while (getline(&line, &cap, f) >= 0) {
+        // skip rule of the reference (:66-77): first non-blank char is '%', or nothing but blanks
+        const char *p = line;
+        while (*p == ' ' || *p == '\t') p++;
+        if (*p == '%' || *p == '\0' || *p == '\n' || *p == '\r') continue;
+        if (header) {  // :79-88
+            sscanf(p, "%llu %llu %llu", &NR, &NC, &NZ);
+            r.reserve(symmetric ? 2 * NZ : NZ);
+            c.reserve(symmetric ? 2 * NZ : NZ);
+            v.reserve(symmetric ? 2 * NZ : NZ);
+            header = false;
+            continue;
+        }
+        // "row col [val]"; strtoull/strtod instead of sscanf: same accepted syntax, much faster
+        char *end = nullptr;
+        unsigned long long row = strtoull(p, &end, 10);
+        unsigned long long col = 0;
+        double val = 1.0;  // pattern entry (:92-93)
+        if (end != p) {
+            const char *q = end;
+            col = strtoull(q, &end, 10);
+            if (end != q) {
+                q = end;
+                double t = strtod(q, &end);
+                if (end != q) val = t;
+            }
+        }
+        r.push_back((uint32_t)(row - 1));  // 1-based -> 0-based (:94)
+        c.push_back((uint32_t)(col - 1));
+        v.push_back(val);
+        if (symmetric && row != col) {  // :95-96
+            r.push_back((uint32_t)(col - 1));
+            c.push_back((uint32_t)(row - 1));
+            v.push_back(val);
+        }
+    }
+    free(line);
+    fclose(f);
+    const size_t n = r.size();
+    *rows = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+    *cols = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+    *vals = (double *)malloc((n ? n : 1) * sizeof(double));
+    if (!*rows || !*cols || !*vals) return fail(OSP_ERR_ALLOC, "host allocation failed");
+    if (n) {
+        memcpy(*rows, r.data(), n * sizeof(uint32_t));
+        memcpy(*cols, c.data(), n * sizeof(uint32_t));
+        memcpy(*vals, v.data(), n * sizeof(double));
+    }
+    *nrow = NR; *ncol = NC; *nnz = n;
+    return OSP_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Counting sort by segment, then order each segment by the inner index; adjacent equal inner
+// indices are the reference's duplicate condition (dupcheck after the sort, :123).
+template <class T>
+int coo_to_compressed(int by_col, uint64_t nseg, uint64_t nnz, const uint32_t *rows, const uint32_t *cols,
+                      const T *vals, int64_t *ptr, uint32_t *idx, T *out_vals) {
+    if (!ptr || (nnz && (!rows || !cols || !vals || !idx || !out_vals))) return fail(OSP_ERR_ARG, "null argument");
+    const uint32_t *seg = by_col ? cols : rows;
+    const uint32_t *in = by_col ? rows : cols;
+    std::fill(ptr, ptr + nseg + 1, (int64_t)0);
+    for (uint64_t i = 0; i < nnz; i++) {
+        if (seg[i] >= nseg) return fail(OSP_ERR_RANGE, "entry %" PRIu64 ": segment index %u >= %" PRIu64, i, seg[i], nseg);
+        ptr[seg[i] + 1]++;
+    }
+    for (uint64_t s = 0; s < nseg; s++) ptr[s + 1] += ptr[s];
+    std::vector<int64_t> cursor(ptr, ptr + nseg);
+    for (uint64_t i = 0; i < nnz; i++) {
+        int64_t o = cursor[seg[i]]++;
+        idx[o] = in[i];
+        out_vals[o] = vals[i];
+    }
+    std::vector<std::pair<uint32_t, T>> tmp;
+    for (uint64_t s = 0; s < nseg; s++) {
+        const int64_t b = ptr[s], e = ptr[s + 1];
+        bool sorted = true;
+        for (int64_t i = b + 1; i < e; i++) if (idx[i] <= idx[i - 1]) { sorted = false; break; }
+        if (!sorted) {
+            tmp.resize(e - b);
+            for (int64_t i = b; i < e; i++) tmp[i - b] = {idx[i], out_vals[i]};
+            std::stable_sort(tmp.begin(), tmp.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+            for (int64_t i = b; i < e; i++) { idx[i] = tmp[i - b].first; out_vals[i] = tmp[i - b].second; }
+            for (int64_t i = b + 1; i < e; i++)
+                if (idx[i] == idx[i - 1])
+                    return fail(OSP_ERR_DUPLICATE, "duplicate coordinate in segment %" PRIu64 " (reference: throw(233))", s);
+        }
+    }
+    return OSP_OK;
+}
+
+template <class T>
+int spgemm_mtx_t(osp_context_t ctx, osp_dtype_t dtype, const char *pa, const char *pb, int transpose_b,
+                 const osp_config_t *cfg, osp_result_t *result) {
+    uint64_t nr[2], nc[2], nz[2];
+    uint32_t *rows[2] = {nullptr, nullptr}, *cols[2] = {nullptr, nullptr};
+    double *vals[2] = {nullptr, nullptr};
+    const char *fn[2] = {pa, pb};
+    int st = OSP_OK;
+    for (int i = 0; i < 2 && st == OSP_OK; i++)
+        st = osp_mtx_read(fn[i], 0, &nr[i], &nc[i], &nz[i], &rows[i], &cols[i], &vals[i]);
+    if (st == OSP_OK) {
+        if (transpose_b) {  // "Workaround: Transpose Matrix 2", :852-856
+            std::swap(nr[1], nc[1]);
+            std::swap(rows[1], cols[1]);
+        }
+        if (nc[0] != nr[1]) st = fail(OSP_ERR_DIM, "inner dimensions differ: A is %" PRIu64 "x%" PRIu64 ", B is %" PRIu64 "x%" PRIu64,
+                                      nr[0], nc[0], nr[1], nc[1]);
+    }
+    if (st == OSP_OK) {
+        const uint64_t K = nc[0];
+        std::vector<T> av(nz[0]), bv(nz[1]), acv(nz[0]), bcv(nz[1]);
+        for (uint64_t i = 0; i < nz[0]; i++) av[i] = (T)vals[0][i];  // value_t(val), :94
+        for (uint64_t i = 0; i < nz[1]; i++) bv[i] = (T)vals[1][i];
+        std::vector<int64_t> ap(K + 1), bp(K + 1);
+        std::vector<uint32_t> ai(nz[0] ? nz[0] : 1), bi(nz[1] ? nz[1] : 1);
+        st = coo_to_compressed<T>(1, K, nz[0], rows[0], cols[0], av.data(), ap.data(), ai.data(), acv.data());  // :878
+        if (st == OSP_OK)
+            st = coo_to_compressed<T>(0, K, nz[1], rows[1], cols[1], bv.data(), bp.data(), bi.data(), bcv.data());  // :879
+        if (st == OSP_OK)
+            st = osp_spgemm_csc_csr(ctx, dtype, nr[0], K, nc[1], ap.data(), ai.data(), acv.data(), bp.data(), bi.data(),
+                                    bcv.data(), OSP_HOST, cfg, result);
+    }
+    for (int i = 0; i < 2; i++) { free(rows[i]); free(cols[i]); free(vals[i]); }
+    return st;
+}
+
+}  // namespace
+
+extern "C" {
+
+int osp_coo_to_compressed_f32(int by_col, uint64_t nseg, uint64_t nnz, const uint32_t *rows, const uint32_t *cols,
+                              const float *vals, int64_t *ptr, uint32_t *idx, float *out_vals) {
+    try { return coo_to_compressed<float>(by_col, nseg, nnz, rows, cols, vals, ptr, idx, out_vals); }
+    catch (const std::exception &e) { return fail(OSP_ERR_ALLOC, "%s", e.what()); }
+}
+int osp_coo_to_compressed_f64(int by_col, uint64_t nseg, uint64_t nnz, const uint32_t *rows, const uint32_t *cols,
+                              const double *vals, int64_t *ptr, uint32_t *idx, double *out_vals) {
+    try { return coo_to_compressed<double>(by_col, nseg, nnz, rows, cols, vals, ptr, idx, out_vals); }
+    catch (const std::exception &e) { return fail(OSP_ERR_ALLOC, "%s", e.what()); }
+}
+
+int osp_spgemm_mtx(osp_context_t ctx, osp_dtype_t dtype, const char *path_a, const char *path_b, int transpose_b,
+                   const osp_config_t *cfg, osp_result_t *result) {
+    if (!ctx || !path_a || !path_b || !result) return fail(OSP_ERR_ARG, "null argument");
+    try {
+        if (dtype == OSP_F32) return spgemm_mtx_t<float>(ctx, dtype, path_a, path_b, transpose_b, cfg, result);
+        if (dtype == OSP_F64) return spgemm_mtx_t<double>(ctx, dtype, path_a, path_b, transpose_b, cfg, result);
+    } catch (const std::exception &e) { return fail(OSP_ERR_ALLOC, "%s", e.what()); }
+    return fail(OSP_ERR_ARG, "dtype must be OSP_F32 or OSP_F64");
+}
+
+int osp_result_write_mtx(osp_result_t r, const char *path) {
+    if (!r || !path) return fail(OSP_ERR_ARG, "null argument");
+    osp_result_info_t info;
+    int st = osp_result_info(r, &info);
+    if (st) return st;
+    try {
+        std::vector<int64_t> rp(info.M + 1);
+        std::vector<uint32_t> ci(info.nnz_c ? info.nnz_c : 1);
+        std::vector<double> vd;
+        std::vector<float> vf;
+        void *vp;
+        if (info.dtype == OSP_F32) { vf.resize(ci.size()); vp = vf.data(); } else { vd.resize(ci.size()); vp = vd.data(); }
+        st = osp_result_copy_csr(r, rp.data(), ci.data(), vp, OSP_HOST);
+        if (st) return st;
+        FILE *f = fopen(path, "w");
+        if (!f) return fail(OSP_ERR_IO, "cannot open %s for writing", path);
+        fprintf(f, "%%%%MatrixMarket matrix coordinate real general\n%%\n%" PRIu64 " %" PRIu64 " %" PRIu64 "\n", info.M, info.N,
+                info.nnz_c);
+        for (uint64_t row = 0; row < info.M; row++)
+            for (int64_t i = rp[row]; i < rp[row + 1]; i++) {
+                if (info.dtype == OSP_F32) fprintf(f, "%" PRIu64 " %u %.9g\n", row + 1, ci[i] + 1, (double)vf[i]);
+                else fprintf(f, "%" PRIu64 " %u %.17g\n", row + 1, ci[i] + 1, vd[i]);
+            }
+        fclose(f);
+    } catch (const std::exception &e) { return fail(OSP_ERR_ALLOC, "%s", e.what()); }
+    return OSP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+"""Host-side Python surface of the MI355X outer-product SpGEMM.
+
+Mirrors the reference's call surface for this path:
+
+* ``spgemm_mtx(a, b)``            -- ``./simulator A.mtx B.mtx`` (``simulator/SimSpGEMM.cpp:819-894``):
+  two MatrixMarket files in, the second operand transposed by default (``:852-856``), CSR out.
+* ``spgemm_csc_csr(...)``         -- ``cscMulcsr(csc, csr)`` + sort/sum (``:265-281``, ``:519-535``).
+* ``spgemm(A, B, transpose_b)``   -- the entry point SURVEY.md section 0 places beside
+  ``NN_models/sparse_util.py``: dense/scipy operands as ``get_mtx_files.py`` dumps them
+  (activation ``batch x in``, ``nn.Linear`` weight ``out x in``) -> ``act @ W.T`` as scipy CSR.
+* ``read_mtx`` / ``coo_to_csr`` / ``coo_to_csc`` -- ``readcoo`` (``:55-100``), ``coo2csr`` (``:102-152``).
+
+All numeric work happens in ``libouterspace_spgemm.so`` on the GPU; nothing here computes.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import OspError  # noqa: F401  (re-export)
+
+_DT = {np.dtype(np.float32): _lib.OSP_F32, np.dtype(np.float64): _lib.OSP_F64}
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data if a.size else 0)
+
+
+class CsrResult:
+    """Library-owned CSR result.  ``rowptr``/``colidx``/``vals`` copy to the host on first use."""
+
+    def __init__(self, ctx, handle):
+        self._ctx, self._h = ctx, handle
+        info = _lib.ResultInfo()
+        _lib.check(_lib.lib().osp_result_info(handle, C.byref(info)))
+        self.info = info.as_dict()
+        self.shape = (info.M, info.N)
+        self.nnz = info.nnz_c
+        self.dtype = np.float32 if info.dtype == _lib.OSP_F32 else np.float64
+        self._host = None
+
+    def to_host(self):
+        if self._host is None:
+            rowptr = np.empty(self.shape[0] + 1, np.int64)
+            colidx = np.empty(self.nnz, np.uint32)
+            vals = np.empty(self.nnz, self.dtype)
+            _lib.check(_lib.lib().osp_result_copy_csr(self._h, _ptr(rowptr), _ptr(colidx), _ptr(vals), _lib.OSP_HOST))
+            self._host = (rowptr, colidx, vals)
+        return self._host
+
+    rowptr = property(lambda self: self.to_host()[0])
+    colidx = property(lambda self: self.to_host()[1])
+    vals = property(lambda self: self.to_host()[2])
+
+    def device_ptrs(self):
+        """(rowptr, colidx, vals) device addresses, valid until ``close()``."""
+        r, c, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(_lib.lib().osp_result_device_ptrs(self._h, C.byref(r), C.byref(c), C.byref(v)))
+        return r.value or 0, c.value or 0, v.value or 0
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        rowptr, colidx, vals = self.to_host()
+        return sp.csr_matrix((vals, colidx.astype(np.int64), rowptr), shape=self.shape)
+
+    def write_mtx(self, path):
+        _lib.check(_lib.lib().osp_result_write_mtx(self._h, os.fsencode(path)))
+
+    def close(self):
+        if self._h is not None:
+            _lib.lib().osp_result_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU + one HIP stream + a buffer pool (``osp_context_t``)."""
+
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        if stream is None:
+            _lib.check(_lib.lib().osp_context_create(device, C.byref(h)))
+        else:
+            _lib.check(_lib.lib().osp_context_create_on_stream(device, C.c_void_p(stream), C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h is not None:
+            _lib.lib().osp_context_destroy(self._h)
+            self._h = None
+
+    def trim(self):
+        _lib.check(_lib.lib().osp_context_trim(self._h))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _config(self, validate, partial_capacity, k_range):
+        cfg = _lib.Config()
+        _lib.lib().osp_config_default(C.byref(cfg))
+        cfg.validate = int(bool(validate))
+        cfg.partial_capacity = int(partial_capacity or 0)
+        if k_range is not None:
+            cfg.k_begin, cfg.k_end = int(k_range[0]), int(k_range[1])
+        return cfg
+
+    def spgemm_csc_csr(self, M, K, N, a_colptr, a_rowidx, a_vals, b_rowptr, b_colidx, b_vals, *,
+                       validate=True, partial_capacity=0, k_range=None):
+        """C = A(CSC) * B(CSR) with numpy (host) operands."""
+        dt = np.dtype(a_vals.dtype)
+        if dt not in _DT or np.dtype(b_vals.dtype) != dt:
+            raise TypeError("values must both be float32 or both float64")
+        arrs = [np.ascontiguousarray(a_colptr, np.int64), np.ascontiguousarray(a_rowidx, np.uint32),
+                np.ascontiguousarray(a_vals, dt), np.ascontiguousarray(b_rowptr, np.int64),
+                np.ascontiguousarray(b_colidx, np.uint32), np.ascontiguousarray(b_vals, dt)]
+        if len(arrs[0]) != K + 1 or len(arrs[3]) != K + 1:
+            # reference: assert(csc.pos.size() == csr.pos.size()), SimSpGEMM.cpp:267
+            raise OspError(_lib.ERR_DIM, f"pointer arrays must have K+1={K + 1} entries "
+                                         f"(got {len(arrs[0])} and {len(arrs[3])})")
+        cfg = self._config(validate, partial_capacity, k_range)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().osp_spgemm_csc_csr(self._h, _DT[dt], M, K, N, *[_ptr(a) for a in arrs],
+                                                 _lib.OSP_HOST, C.byref(cfg), C.byref(h)))
+        return CsrResult(self, h)
+
+    def spgemm_csc_csr_device(self, dtype, M, K, N, ptrs, *, validate=False, partial_capacity=0, k_range=None):
+        """Same with six DEVICE addresses (ints): a_colptr, a_rowidx, a_vals, b_rowptr, b_colidx, b_vals."""
+        cfg = self._config(validate, partial_capacity, k_range)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().osp_spgemm_csc_csr(self._h, _DT[np.dtype(dtype)], M, K, N,
+                                                 *[C.c_void_p(int(p)) for p in ptrs], _lib.OSP_DEVICE,
+                                                 C.byref(cfg), C.byref(h)))
+        return CsrResult(self, h)
+
+    def merge_csr_parts(self, M, N, parts, *, partial_capacity=0):
+        """Sum CSR matrices of equal shape.  parts: list of (rowptr, colidx, vals) numpy triples."""
+        dt = np.dtype(parts[0][2].dtype)
+        keep, n = [], len(parts)
+        rp, ci, va = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+        for i, (r, c, v) in enumerate(parts):
+            r = np.ascontiguousarray(r, np.int64); c = np.ascontiguousarray(c, np.uint32); v = np.ascontiguousarray(v, dt)
+            keep += [r, c, v]
+            rp[i], ci[i], va[i] = r.ctypes.data, (c.ctypes.data if c.size else 0), (v.ctypes.data if v.size else 0)
+        cfg = self._config(False, partial_capacity, None)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().osp_merge_csr_parts(self._h, _DT[dt], M, N, n, rp, ci, va, _lib.OSP_HOST,
+                                                  C.byref(cfg), C.byref(h)))
+        return CsrResult(self, h)
+
+    def merge_csr_parts_device(self, dtype, M, N, part_ptrs, *, partial_capacity=0):
+        """Device-resident parts: list of (rowptr, colidx, vals) device addresses."""
+        n = len(part_ptrs)
+        rp, ci, va = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+        for i, (r, c, v) in enumerate(part_ptrs):
+            rp[i], ci[i], va[i] = int(r), int(c), int(v)
+        cfg = self._config(False, partial_capacity, None)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().osp_merge_csr_parts(self._h, _DT[np.dtype(dtype)], M, N, n, rp, ci, va,
+                                                  _lib.OSP_DEVICE, C.byref(cfg), C.byref(h)))
+        return CsrResult(self, h)
+
+    def spgemm_mtx(self, path_a, path_b, transpose_b=True, dtype=np.float32, *, validate=True, partial_capacity=0):
+        """The reference CLI's data flow: two .mtx files in, A * B^T (default) out."""
+        cfg = self._config(validate, partial_capacity, None)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().osp_spgemm_mtx(self._h, _DT[np.dtype(dtype)], os.fsencode(path_a), os.fsencode(path_b),
+                                             int(bool(transpose_b)), C.byref(cfg), C.byref(h)))
+        return CsrResult(self, h)
+
+
+# ---- ingest helpers (host, no GPU) ---------------------------------------------------------------
+def read_mtx(path, symmetric=False):
+    """``readcoo`` (SimSpGEMM.cpp:55-100): returns (nrow, ncol, rows u32, cols u32, vals f64)."""
+    L = _lib.lib()
+    nrow, ncol, nnz = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    r, c, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _lib.check(L.osp_mtx_read(os.fsencode(path), int(symmetric), C.byref(nrow), C.byref(ncol), C.byref(nnz),
+                              C.byref(r), C.byref(c), C.byref(v)))
+    n = nnz.value
+    try:
+        rows = np.ctypeslib.as_array(C.cast(r, C.POINTER(C.c_uint32)), (max(n, 1),))[:n].copy()
+        cols = np.ctypeslib.as_array(C.cast(c, C.POINTER(C.c_uint32)), (max(n, 1),))[:n].copy()
+        vals = np.ctypeslib.as_array(C.cast(v, C.POINTER(C.c_double)), (max(n, 1),))[:n].copy()
+    finally:
+        for p in (r, c, v):
+            L.osp_host_free(p)
+    return nrow.value, ncol.value, rows, cols, vals
+
+
+def _compress(by_col, nseg, rows, cols, vals):
+    dt = np.dtype(vals.dtype)
+    if dt not in _DT:
+        raise TypeError("values must be float32 or float64")
+    rows = np.ascontiguousarray(rows, np.uint32); cols = np.ascontiguousarray(cols, np.uint32)
+    vals = np.ascontiguousarray(vals)
+    nnz = len(rows)
+    ptr = np.zeros(nseg + 1, np.int64); idx = np.zeros(nnz, np.uint32); out = np.zeros(nnz, dt)
+    fn = getattr(_lib.lib(), "osp_coo_to_compressed_f32" if dt == np.float32 else "osp_coo_to_compressed_f64")
+    _lib.check(fn(int(by_col), nseg, nnz, _ptr(rows), _ptr(cols), _ptr(vals), _ptr(ptr), _ptr(idx), _ptr(out)))
+    return ptr, idx, out
+
+
+def coo_to_csr(nrow, rows, cols, vals):
+    """``coo2csr<false>`` (SimSpGEMM.cpp:102-152); duplicate coordinates raise OspError(233)."""
+    return _compress(0, nrow, rows, cols, vals)
+
+
+def coo_to_csc(ncol, rows, cols, vals):
+    """``coo2csr<true>`` (SimSpGEMM.cpp:102-152)."""
+    return _compress(1, ncol, rows, cols, vals)
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def _as_coo(x):
+    """dense ndarray / torch tensor / scipy sparse -> (nrow, ncol, rows, cols, vals)."""
+    import scipy.sparse as sp
+    if hasattr(x, "detach"):
+        x = x.detach().cpu().numpy()
+    if not sp.issparse(x):
+        x = sp.csr_matrix(np.asarray(x))  # what util.py:61-62 does before mmwrite
+    x = x.tocoo()
+    return x.shape[0], x.shape[1], x.row.astype(np.uint32), x.col.astype(np.uint32), x.data
+
+
+def spgemm(A, B, transpose_b=True, ctx=None, dtype=None):
+    """``A @ B.T`` (default, as the reference CLI) or ``A @ B`` as scipy CSR, computed on the GPU."""
+    ctx = ctx or default_context()
+    M, K, ar, ac, av = _as_coo(A)
+    br_n, bc_n, br, bc, bv = _as_coo(B)
+    if transpose_b:
+        br_n, bc_n, br, bc = bc_n, br_n, bc, br
+    if br_n != K:
+        raise OspError(_lib.ERR_DIM, f"inner dimensions differ: A is {M}x{K}, B is {br_n}x{bc_n}")
+    dt = np.dtype(dtype or np.result_type(av.dtype, bv.dtype))
+    if dt not in _DT:
+        dt = np.dtype(np.float64)
+    a = coo_to_csc(K, ar, ac, av.astype(dt))
+    b = coo_to_csr(K, br, bc, bv.astype(dt))
+    with_res = ctx.spgemm_csc_csr(M, K, bc_n, *a, *b)
+    out = with_res.to_scipy()
+    with_res.close()
+    return out
