@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: output nnz/s of C = A*A for an R-MAT matrix (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W            # one MI355X
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # k-sharded
+
+A "step" is one complete product with the operands already resident in HBM: symbolic chunk
+layout, multiply, merge, compaction into CSR (and, for N > 1, the exchange of partial CSRs over
+RCCL and the final per-row merge).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scale", type=int, default=22)
+    ap.add_argument("--edge-factor", type=int, default=16)
+    ap.add_argument("--rmat", default="uniform", help="uniform | mild | g500 | a,b,c,d")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--dtype", default="f64", choices=["f32", "f64"])
+    ap.add_argument("--partial-capacity", type=int, default=0)
+    ap.add_argument("--cpu-baseline", type=int, default=1, help="time the CPU reference on a k-slab (rank 0, N=1)")
+    ap.add_argument("--cpu-partials", type=float, default=6e7, help="partial products in the CPU sample slab")
+    return ap.parse_args()
+
+
+def rmat_device(scale, ef, abcd, seed, device, dtype):
+    """R-MAT on the GPU (same recipe as outerspace_amd.generators.rmat_coo), duplicates removed.
+    Returns CSR and CSC arrays of the same matrix as torch tensors (int64 ptr, int32 idx)."""
+    import torch
+    a, b, c, _ = abcd
+    n, m = 1 << scale, ef << scale
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    rows = torch.zeros(m, dtype=torch.int64, device=device)
+    cols = torch.zeros(m, dtype=torch.int64, device=device)
+    for _ in range(scale):
+        u = torch.rand(m, generator=g, device=device, dtype=torch.float64)
+        rbit = u >= a + b
+        cbit = ((u >= a) & (u < a + b)) | (u >= a + b + c)
+        rows = (rows << 1) | rbit
+        cols = (cols << 1) | cbit
+        del u, rbit, cbit
+    key = torch.unique(rows * n + cols)  # sorted: row-major
+    del rows, cols
+    rows, cols = key // n, key % n
+    del key
+    vals = torch.rand(rows.numel(), generator=g, device=device, dtype=dtype) + 0.5
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+    colptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    colptr[1:] = torch.cumsum(torch.bincount(cols, minlength=n), 0)
+    perm = torch.argsort(cols * n + rows)
+    csr = (rowptr, cols.to(torch.int32).contiguous(), vals)
+    csc = (colptr, rows[perm].to(torch.int32).contiguous(), vals[perm].contiguous())
+    del perm, rows, cols
+    return n, csr, csc
+
+
+def cpu_baseline(csc, csr, n, target_partials, np_dtype):
+    """Time the reference algorithm (cscMulcsr + sort/sum, SimSpGEMM.cpp:265-281,:519-535) on one host
+    core over a contiguous k-slab holding about `target_partials` partial products."""
+    import torch
+    from oracle import oracle  # checker / baseline only
+    colptr, rowidx, avals = csc
+    rowptr, colidx, bvals = csr
+    w = (colptr[1:] - colptr[:-1]) * (rowptr[1:] - rowptr[:-1])
+    cum = torch.cumsum(w, 0)
+    total = int(cum[-1])
+    k1 = int(torch.searchsorted(cum, torch.tensor([int(min(target_partials, total))], device=cum.device))[0]) + 1
+    k1 = max(1, min(k1, n))
+    a0, a1 = 0, int(colptr[k1])
+    b0, b1 = 0, int(rowptr[k1])
+    ac = colptr[:k1 + 1].cpu().numpy()
+    bc = rowptr[:k1 + 1].cpu().numpy()
+    ai = rowidx[a0:a1].cpu().numpy().view(np.uint32)
+    av = avals[a0:a1].cpu().numpy().astype(np_dtype)
+    bi = colidx[b0:b1].cpu().numpy().view(np.uint32)
+    bv = bvals[b0:b1].cpu().numpy().astype(np_dtype)
+    if oracle.have_ref():
+        kind = "reference"
+        r = oracle.ref(np_dtype).spgemm_csx(k1, ac, ai, av, bc, bi, bv, timing_only=True)
+        nnzc, P, secs = r["nnzc"], r["partials"], sum(r["secs"])
+    else:
+        kind = "port"
+        r = oracle.port().spgemm(n, k1, n, ac, ai, av, bc, bi, bv)
+        nnzc, P, secs = len(r["colidx"]), r["partials"], sum(r["secs"])
+    return {"value": nnzc / secs, "unit": "nnz/s", "cores": 1, "kind": kind,
+            "sample": f"k-slab [0,{k1}) of the same matrix: {P} partial products -> {nnzc} nnz in {secs:.2f} s "
+                      f"({P / secs / 1e6:.2f} M partials/s); host has {os.cpu_count()} cores, the reference is single-threaded",
+            "partials_per_s": P / secs, "seconds": secs}
+
+
+def main():
+    args = parse()
+    import torch
+    from outerspace_amd import generators as gen
+    from outerspace_amd import spgemm as S
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    abcd = gen.RMAT_PRESETS[args.rmat] if args.rmat in gen.RMAT_PRESETS else tuple(float(x) for x in args.rmat.split(","))
+    tdtype = torch.float64 if args.dtype == "f64" else torch.float32
+    np_dtype = np.float64 if args.dtype == "f64" else np.float32
+    E = 4 + np.dtype(np_dtype).itemsize
+
+    n, csr, csc = rmat_device(args.scale, args.edge_factor, abcd, args.seed, device, tdtype)
+    nnz_a = int(csr[0][-1])
+    torch.cuda.synchronize()
+    ctx = S.Context(local_rank)
+    ptrs = [t.data_ptr() for t in (*csc, *csr)]
+
+    if world == 1:
+        def step():
+            res = ctx.spgemm_csc_csr_device(np_dtype, n, n, n, ptrs, validate=False,
+                                            partial_capacity=args.partial_capacity)
+            info = res.info
+            res.close()
+            return info
+    else:
+        from outerspace_amd import distributed as D
+        plan = D.plan_k_shards(csc[0], csr[0], world)
+
+        def step():
+            return D.spgemm_k_sharded(ctx, np_dtype, n, n, n, csc, csr, plan, dist, rank, world,
+                                      partial_capacity=args.partial_capacity)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    infos = [step() for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    info = infos[-1]
+    nnz_c, P = info["nnz_c_global"] if world > 1 else info["nnz_c"], info["partials_global"] if world > 1 else info["partials"]
+    ms_step = dt / args.steps * 1e3
+
+    if rank == 0:
+        # per-kernel roofline: algorithmic bytes per launch / mean launch duration
+        def mean(key):
+            return float(np.mean([i[key] for i in infos]))
+        Pl, nnz_cl, nnz_al = info["partials"], info["nnz_c"], info["nnz_a"]  # this rank's shard
+        kernels = {}
+        nmul = max(1, info["multiply_launches"])
+        nmer = max(1, info["merge_launches"])
+        mul_bytes = (E * (nnz_al + info["nnz_b"]) + 2 * 8 * (n + 1) + E * Pl) / nmul
+        mer_bytes = (E * Pl + E * nnz_cl + 8 * (n + 1)) / nmer
+        for name, nbytes, ms, nl in (("multiply_kernel", mul_bytes, mean("ms_multiply_kernel"), nmul),
+                                     ("merge_tiles_kernel", mer_bytes, mean("ms_merge_kernel"), nmer)):
+            per = ms / nl
+            kernels[name] = {"algorithmic_bytes_per_launch": nbytes, "ms_per_launch": per, "launches_per_step": nl,
+                             "GBps": (nbytes / (per * 1e-3) / 1e9) if per > 0 else 0.0}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
+        roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"],
+                "ms_per_launch": kernels[dom]["ms_per_launch"], "kernels": kernels}
+        out = {
+            "metric": "spgemm_output_nnz_per_s", "value": nnz_c / (ms_step * 1e-3), "unit": "nnz/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"R-MAT scale-{args.scale} edge-factor-{args.edge_factor} (a,b,c,d)={abcd} seed {args.seed}, "
+                                   f"duplicates removed, self-product C=A*A, CSC x CSR -> CSR",
+                       "n": n, "nnz_a": nnz_a, "partials": P, "nnz_c": nnz_c,
+                       "parallelism": "single GPU" if world == 1 else f"k-sharded over {world} GPUs + RCCL all-to-all of partial CSRs"},
+            "gflops": 2 * P / (ms_step * 1e-3) / 1e9, "partials_per_s": P / (ms_step * 1e-3),
+            "phases_ms": {k: mean(k) for k in ("ms_symbolic", "ms_multiply", "ms_merge", "ms_compact", "ms_total")},
+            "panels": info["panels"], "heavy_rows": info["heavy_rows"], "heavy_partials": info["heavy_partials"],
+            "roofline": roof,
+        }
+        if world > 1:
+            out["phases_ms"].update({k: mean(k) for k in ("ms_exchange", "ms_final_merge") if k in info})
+        if world == 1 and args.cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(csc, csr, n, args.cpu_partials, np_dtype)
+            out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

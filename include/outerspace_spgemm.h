@@ -79,8 +79,9 @@ typedef struct osp_result_info {
     uint64_t light_tiles;       /* merge tiles reduced in LDS */
     uint64_t heavy_rows;        /* rows reduced by the global-sort path */
     uint64_t heavy_partials;
-    float ms_symbolic, ms_multiply, ms_merge, ms_compact, ms_total;
-    uint32_t multiply_launches, merge_launches;
+    float ms_symbolic, ms_multiply, ms_merge, ms_compact, ms_total;   /* phases (all launches in them) */
+    float ms_multiply_kernel, ms_merge_kernel;  /* multiply_kernel / merge_tiles_kernel launches alone */
+    uint32_t multiply_launches, merge_launches; /* number of those launches */
     int dtype;
 } osp_result_info_t;
 

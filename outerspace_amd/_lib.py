@@ -36,6 +36,7 @@ class ResultInfo(C.Structure):
                 ("heavy_rows", C.c_uint64), ("heavy_partials", C.c_uint64),
                 ("ms_symbolic", C.c_float), ("ms_multiply", C.c_float), ("ms_merge", C.c_float),
                 ("ms_compact", C.c_float), ("ms_total", C.c_float),
+                ("ms_multiply_kernel", C.c_float), ("ms_merge_kernel", C.c_float),
                 ("multiply_launches", C.c_uint32), ("merge_launches", C.c_uint32), ("dtype", C.c_int)]
 
     def as_dict(self):

@@ -121,7 +121,7 @@ struct Result {
 
 struct PhaseTimer {
     hipStream_t s;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[6];
     explicit PhaseTimer(hipStream_t st) : s(st) {}
     ~PhaseTimer() {
         for (auto &v : ev) for (auto &p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -140,7 +140,7 @@ struct PhaseTimer {
         return t;
     }
 };
-enum { PH_SYM = 0, PH_MUL = 1, PH_MERGE = 2, PH_COMPACT = 3 };
+enum { PH_SYM = 0, PH_MUL = 1, PH_MERGE = 2, PH_COMPACT = 3, PH_MUL_K = 4, PH_MERGE_K = 5 };
 
 static inline unsigned grid_for(uint64_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 static inline int bits_for(uint64_t n) {  // bits needed to represent values in [0, n)
@@ -161,7 +161,7 @@ template <class T> struct Producer {
     virtual ~Producer() {}
     // enqueue kernels that fill pcol/pval[0 .. row_off[r1]-row_off[r0]) for rows [r0,r1)
     virtual void produce(uint64_t r0, uint64_t r1, bool whole, uint64_t base, uint64_t count,
-                         uint32_t *pcol, T *pval) = 0;
+                         uint32_t *pcol, T *pval, PhaseTimer &tm) = 0;
 };
 
 // ---- stages shared by both entry points: partial products of each row -> final CSR ----------------
@@ -240,7 +240,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         const uint64_t count = (npanels == 1) ? P : h_off[r1] - base;
         // ---- multiply (or scatter of CSR parts) ----
         tm.begin(PH_MUL);
-        if (count) prod.produce(r0, r1, npanels == 1, base, count, pcol, pval);
+        if (count) prod.produce(r0, r1, npanels == 1, base, count, pcol, pval, tm);
         tm.end(PH_MUL);
         // ---- merge ----
         tm.begin(PH_MERGE);
@@ -253,8 +253,10 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         compact_flagged_kernel<HeavyRowFlag><<<grid_for(nr, 256), 256, 0, s>>>(hrf, flag_scan, nr, r0, heavy_rows);
         const uint32_t nheavy = d2h(flag_scan + nr, s);
         if (ntiles) {
+            tm.begin(PH_MERGE_K);
             merge_tiles_kernel<T><<<ntiles, kMergeThreads, 0, s>>>(tile_rows, ntiles, r1, d_row_off, base, colbits,
                                                                   pcol, pval, row_nnz, row_src);
+            tm.end(PH_MERGE_K);
             res->info.merge_launches++;
         }
         res->info.light_tiles += ntiles - nheavy;
@@ -283,7 +285,6 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
                                                                      hoff, nheavy, d_row_off, base, colbits, pcol, pval);
             heavy_rows_kernel<<<grid_for(nheavy, 256), 256, 0, s>>>(heavy_rows, hoff, nheavy, headscan, d_row_off, base,
                                                                     row_nnz, row_src);
-            res->info.merge_launches += 4;
         }
         tm.end(PH_MERGE);
         // ---- compaction into the final CSR ----
@@ -334,16 +335,18 @@ template <class T> struct OuterProducer : Producer<T> {
     const uint64_t *chunk_off;
     int64_t *a_start; uint32_t *a_cnt; uint64_t *prod; uint64_t *prod_off; uint64_t *scan_tmp;
     void produce(uint64_t r0, uint64_t r1, bool whole, uint64_t base, uint64_t count, uint32_t *pcol,
-                 T *pval) override {
+                 T *pval, PhaseTimer &tm) override {
         hipStream_t s = ctx->stream;
         const uint64_t nk = k1 - k0;
         panel_columns_kernel<<<grid_for(nk, 256), 256, 0, s>>>(a_colptr, a_rowidx, b_rowptr, k0, nk, (uint32_t)r0, r1,
                                                                whole ? 1 : 0, a_start, a_cnt, prod);
         device_exclusive_scan<LoadU64, uint64_t>(LoadU64{prod}, nk, prod_off, scan_tmp, s);
         const uint64_t nblocks = (count + kMulPerBlock - 1) / kMulPerBlock;
+        tm.begin(PH_MUL_K);
         multiply_kernel<T><<<(unsigned)nblocks, kMulThreads, 0, s>>>(a_vals, b_colidx, b_vals, b_rowptr, chunk_off, e0,
                                                                      a_start, a_cnt, prod_off, k0, nk, count, base, pcol,
                                                                      pval);
+        tm.end(PH_MUL_K);
         res->info.multiply_launches++;
     }
 };
@@ -353,7 +356,8 @@ template <class T> struct PartsProducer : Producer<T> {
     const int64_t *const *d_rowptrs; const uint32_t *const *d_colidxs; const T *const *d_valss;
     int nparts;
     const uint64_t *row_off;
-    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, uint32_t *pcol, T *pval) override {
+    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, uint32_t *pcol, T *pval,
+                 PhaseTimer &) override {
         const uint64_t nr = r1 - r0;
         parts_scatter_kernel<T><<<grid_for(nr * kWave, 256), 256, 0, ctx->stream>>>(d_rowptrs, d_colidxs, d_valss, nparts,
                                                                                     r0, r1, row_off, base, pcol, pval);
@@ -476,6 +480,8 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     res->info.ms_multiply = tm.total(PH_MUL);
     res->info.ms_merge = tm.total(PH_MERGE);
     res->info.ms_compact = tm.total(PH_COMPACT);
+    res->info.ms_multiply_kernel = tm.total(PH_MUL_K);
+    res->info.ms_merge_kernel = tm.total(PH_MERGE_K);
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
 }
@@ -530,6 +536,8 @@ static void merge_parts_impl(Context *ctx, Result *res, uint64_t M, uint64_t N, 
     res->info.ms_multiply = tm.total(PH_MUL);
     res->info.ms_merge = tm.total(PH_MERGE);
     res->info.ms_compact = tm.total(PH_COMPACT);
+    res->info.ms_multiply_kernel = tm.total(PH_MUL_K);
+    res->info.ms_merge_kernel = tm.total(PH_MERGE_K);
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
 }

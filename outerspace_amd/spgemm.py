@@ -14,6 +14,7 @@ All numeric work happens in ``libouterspace_spgemm.so`` on the GPU; nothing here
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -32,6 +33,7 @@ class CsrResult:
 
     def __init__(self, ctx, handle):
         self._ctx, self._h = ctx, handle
+        ctx._results.add(self)  # a context closes its results before it goes away
         info = _lib.ResultInfo()
         _lib.check(_lib.lib().osp_result_info(handle, C.byref(info)))
         self.info = info.as_dict()
@@ -83,6 +85,8 @@ class Context:
     """One GPU + one HIP stream + a buffer pool (``osp_context_t``)."""
 
     def __init__(self, device=0, stream=None):
+        self._h = None
+        self._results = weakref.WeakSet()
         h = C.c_void_p()
         if stream is None:
             _lib.check(_lib.lib().osp_context_create(device, C.byref(h)))
@@ -93,6 +97,8 @@ class Context:
 
     def close(self):
         if self._h is not None:
+            for r in list(self._results):
+                r.close()
             _lib.lib().osp_context_destroy(self._h)
             self._h = None
 
