@@ -34,7 +34,9 @@ def parse():
     ap.add_argument("--dtype", default="f64", choices=["f32", "f64"])
     ap.add_argument("--partial-capacity", type=int, default=0)
     ap.add_argument("--cpu-baseline", type=int, default=1, help="time the CPU reference on a k-slab (rank 0, N=1)")
-    ap.add_argument("--cpu-partials", type=float, default=6e7, help="partial products in the CPU sample slab")
+    ap.add_argument("--cpu-partials", type=float, default=2.5e8, help="partial products in the CPU sample slab")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal only: exchange staged through host memory, ranks may share a GPU")
     return ap.parse_args()
 
 
@@ -116,12 +118,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     abcd = gen.RMAT_PRESETS[args.rmat] if args.rmat in gen.RMAT_PRESETS else tuple(float(x) for x in args.rmat.split(","))
     tdtype = torch.float64 if args.dtype == "f64" else torch.float32
@@ -131,7 +137,7 @@ def main():
     n, csr, csc = rmat_device(args.scale, args.edge_factor, abcd, args.seed, device, tdtype)
     nnz_a = int(csr[0][-1])
     torch.cuda.synchronize()
-    ctx = S.Context(local_rank)
+    ctx = S.Context(dev_index)
     ptrs = [t.data_ptr() for t in (*csc, *csr)]
 
     if world == 1:
@@ -147,7 +153,8 @@ def main():
 
         def step():
             return D.spgemm_k_sharded(ctx, np_dtype, n, n, n, csc, csr, plan, dist, rank, world,
-                                      partial_capacity=args.partial_capacity)
+                                      partial_capacity=args.partial_capacity,
+                                      stage_through_host=args.dist_backend == "gloo")
 
     for _ in range(args.warmup):
         step()
@@ -161,7 +168,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     info = infos[-1]

@@ -1,0 +1,99 @@
+"""CPU-side checks of the boundary: the library loads, exports every symbol the header declares, the
+host-only entry points (reader, COO->compressed) match the reference's goldens, and with no GPU the
+compute entry points fail loudly instead of falling back."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from outerspace_amd import _lib
+from outerspace_amd import spgemm as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported():
+    hdr = open(os.path.join(ROOT, "include", "outerspace_spgemm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)  # declarations only, not prose in comments
+    declared = set(re.findall(r"\b(osp_[a-z0-9_]+)\s*\(", hdr))
+    L = _lib.lib()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert declared == set(_lib.EXPORTS)
+
+
+def test_struct_layouts_match_header():
+    import ctypes
+    # osp_config_t: int, u64, u64, u64, int[8]; osp_result_info_t ends with two u32 and an int
+    assert ctypes.sizeof(_lib.Config) == 8 + 8 + 8 + 8 + 32
+    cfg = _lib.Config()
+    _lib.lib().osp_config_default(ctypes.byref(cfg))
+    assert cfg.validate == 1 and cfg.partial_capacity == 0 and cfg.k_end == 0
+    assert _lib.lib().osp_status_string(233).decode().startswith("duplicate")
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(S.OspError) as ei:
+        S.Context(0)
+    assert ei.value.status == _lib.ERR_HIP and "no CPU path" in str(ei.value)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "outerspace_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                # comments may mention the oracle; code must never import, load or link it
+                assert not re.search(r"import\s+oracle|from\s+oracle|liboracle|oracle[/.]|_ref/|libref", text), (dirpath, f)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_reader_matches_reference_golden(golden_dir, dt):
+    g = np.load(os.path.join(golden_dir, "reader_quirks_expected.npz"))
+    nrow, ncol, r, c, v = S.read_mtx(os.path.join(golden_dir, "reader_quirks.mtx"))
+    s = np.dtype(dt).name
+    assert (nrow, ncol) == (int(g["nrow"]), int(g["ncol"]))
+    assert np.array_equal(r, g[f"rows_{s}"]) and np.array_equal(c, g[f"cols_{s}"])
+    assert np.array_equal(v.astype(dt), g[f"vals_{s}"])
+
+
+def test_reader_c1_and_mlp_files(golden_dir, port):
+    for name in ("c1_A.mtx", "mlp_fc1_weight.mtx"):
+        a = S.read_mtx(os.path.join(golden_dir, name))
+        b = port.readcoo(os.path.join(golden_dir, name))
+        assert a[:2] == b[:2]
+        for x, y in zip(a[2:], b[2:]):
+            assert np.array_equal(x, y)
+    with pytest.raises(S.OspError) as ei:
+        S.read_mtx(os.path.join(golden_dir, "does_not_exist.mtx"))
+    assert ei.value.status == _lib.ERR_IO
+
+
+def test_host_conversion_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "edges_expected.npz"))
+    for tr, nseg, fn in ((0, 6, S.coo_to_csr), (1, 8, S.coo_to_csc)):
+        ptr, idx, val = fn(nseg, g["conv_rows"], g["conv_cols"], g["conv_vals"])
+        assert np.array_equal(ptr, g[f"conv{tr}_pos"]) and np.array_equal(idx, g[f"conv{tr}_idx"])
+        assert np.array_equal(val, g[f"conv{tr}_val"])
+    for fn in (S.coo_to_csr, S.coo_to_csc):
+        with pytest.raises(S.OspError) as ei:
+            fn(3, g["dup_rows"], g["dup_cols"], g["dup_vals"])
+        assert ei.value.status == 233
+    # documented divergence from the reference's back-fill quirk (SimSpGEMM.cpp:143-148)
+    ptr, idx, _ = S.coo_to_csr(4, g["onerow_rows"], g["onerow_cols"], g["onerow_vals"])
+    assert np.array_equal(ptr, [0, 0, 0, 3, 3]) and np.array_equal(idx, [0, 1, 3])
+    with pytest.raises(S.OspError) as ei:
+        S.coo_to_csr(2, np.array([5], np.uint32), np.array([0], np.uint32), np.array([1.0]))
+    assert ei.value.status == _lib.ERR_RANGE
+    # rect case: conversion equals the reference's coo2csr for both orientations and value types
+    for dt in (np.float32, np.float64):
+        s = np.dtype(dt).name
+        a = S.coo_to_csc(7, g["rect_a_rows"], g["rect_a_cols"], g["rect_a_vals"].astype(dt))
+        b = S.coo_to_csr(7, g["rect_b_rows"], g["rect_b_cols"], g["rect_b_vals"].astype(dt))
+        for got, key in zip((*a, *b), ("apos", "aidx", "aval", "bpos", "bidx", "bval")):
+            assert np.array_equal(got, g[f"rect_{key}_{s}"]), key
