@@ -17,6 +17,7 @@
 #include "../../include/outerspace_spgemm.h"
 #include "osp_internal.h"
 #include "osp_kernels.h"
+#include "osp_merge_runs.h"
 
 namespace osp {
 
@@ -167,12 +168,17 @@ template <class T> struct Producer {
 // ---- stages shared by both entry points: partial products of each row -> final CSR ----------------
 template <class T>
 static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_t M, uint64_t N,
-                           const uint64_t *d_row_off, uint64_t P, uint64_t cap_cfg, PhaseTimer &tm) {
+                           const uint64_t *d_row_off, const uint32_t *d_arow, const uint64_t *d_chunk_start,
+                           uint64_t P, uint64_t cap_cfg, PhaseTimer &tm) {
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
-    constexpr uint32_t kCap = TileCap<T>::value;
+    // merge algorithm of the LDS tiles: stable 9-bit LSD radix sort (default) or pairwise merging of the
+    // pre-sorted chunks (osp_merge_runs.h).  Measured on MI355X with tools/bench_merge: radix 4.95 ms vs
+    // runs 6.9 ms per 2.7e8 partial products (16 chunks of 16 per row), so radix is what ships.
+    constexpr uint32_t kCap = kMergeByRuns ? (uint32_t)RunCap<T>::value : (uint32_t)TileCap<T>::value;
     const int colbits = std::max(1, bits_for(N));
-    const uint32_t max_rows = (uint32_t)std::min<uint64_t>(kTileMaxRows, colbits >= 32 ? 1ull : (1ull << (32 - colbits)));
+    const uint32_t max_rows = kMergeByRuns ? (uint32_t)kTileMaxRows
+                                           : (uint32_t)std::min<uint64_t>(kTileMaxRows, colbits >= 32 ? 1ull : (1ull << (32 - colbits)));
 
     res->rowptr = (int64_t *)ctx->alloc((M + 1) * sizeof(int64_t));
     if (P == 0) {
@@ -222,17 +228,28 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     }
     uint32_t *pcol = sc.get<uint32_t>(max_panel);
     T *pval = sc.get<T>(max_panel);
-    uint32_t *row_nnz = sc.get<uint32_t>(M);
-    uint64_t *row_src = sc.get<uint64_t>(M);
+    uint32_t *heavy_nnz = sc.get<uint32_t>(M);
     uint32_t *flag_scan = sc.get<uint32_t>(max_rows_panel + 1);
     uint32_t *tile_rows = sc.get<uint32_t>(max_rows_panel + 1);
     uint32_t *heavy_rows = sc.get<uint32_t>(max_rows_panel + 1);
-    uint64_t *c_local = sc.get<uint64_t>(max_rows_panel + 1);
-    uint64_t *scan_tmp = sc.get<uint64_t>(scan_scratch_entries(std::max<uint64_t>(max_rows_panel + 1, 16)));
+    uint64_t *tile_status = sc.get<uint64_t>(max_rows_panel + 1);
+    uint64_t *scan_tmp = sc.get<uint64_t>(scan_scratch_entries(std::max<uint64_t>(M + 1, 16)));
+    uint64_t *out_nnz = sc.get<uint64_t>((uint64_t)npanels + 1);  // nnz written before panel p
+    uint32_t *ticket = sc.get<uint32_t>(1);
+    OSP_HIP(hipMemsetAsync(out_nnz, 0, sizeof(uint64_t), s));
 
-    struct Piece { uint32_t *col; T *val; uint64_t nnz; };
-    std::vector<Piece> pieces;
-    uint64_t nnz_total = 0;
+    // final CSR arrays at an upper bound: nnz(C) <= sum_i min(U_i, N)
+    uint64_t cap_c;
+    {
+        Scratch us(ctx);
+        uint64_t *ub = us.get<uint64_t>(M + 1);
+        device_exclusive_scan<RowUpperBound, uint64_t>(RowUpperBound{d_row_off, N}, M, ub, scan_tmp, s);
+        cap_c = d2h(ub + M, s);
+    }
+    res->colidx = (uint32_t *)ctx->alloc(std::max<uint64_t>(cap_c, 1) * sizeof(uint32_t));
+    res->vals = ctx->alloc(std::max<uint64_t>(cap_c, 1) * sizeof(T));
+    uint32_t *c_col = res->colidx;
+    T *c_val = (T *)res->vals;
 
     for (uint32_t p = 0; p < npanels; p++) {
         const uint64_t r0 = bounds[p], r1 = bounds[p + 1], nr = r1 - r0;
@@ -252,15 +269,9 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         device_exclusive_scan<HeavyRowFlag, uint32_t>(hrf, nr, flag_scan, (uint32_t *)scan_tmp, s);
         compact_flagged_kernel<HeavyRowFlag><<<grid_for(nr, 256), 256, 0, s>>>(hrf, flag_scan, nr, r0, heavy_rows);
         const uint32_t nheavy = d2h(flag_scan + nr, s);
-        if (ntiles) {
-            tm.begin(PH_MERGE_K);
-            merge_tiles_kernel<T><<<ntiles, kMergeThreads, 0, s>>>(tile_rows, ntiles, r1, d_row_off, base, colbits,
-                                                                  pcol, pval, row_nnz, row_src);
-            tm.end(PH_MERGE_K);
-            res->info.merge_launches++;
-        }
         res->info.light_tiles += ntiles - nheavy;
         if (nheavy) {
+            // rows longer than one LDS tile: global stable sort on (row rank, col), run sums in place
             Scratch hs(ctx);
             uint64_t *hoff = hs.get<uint64_t>((uint64_t)nheavy + 1);
             uint64_t *hscan_tmp = hs.get<uint64_t>(scan_scratch_entries(nheavy));
@@ -283,45 +294,44 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
             device_exclusive_scan<HeavyHeadFlag, uint64_t>(HeavyHeadFlag{keys[cur]}, nh, headscan, headscan_tmp, s);
             heavy_reduce_kernel<T><<<grid_for(nh, 256), 256, 0, s>>>(keys[cur], sorted_val, headscan, nh, heavy_rows,
                                                                      hoff, nheavy, d_row_off, base, colbits, pcol, pval);
-            heavy_rows_kernel<<<grid_for(nheavy, 256), 256, 0, s>>>(heavy_rows, hoff, nheavy, headscan, d_row_off, base,
-                                                                    row_nnz, row_src);
+            heavy_rows_kernel<<<grid_for(nheavy, 256), 256, 0, s>>>(heavy_rows, hoff, nheavy, headscan, heavy_nnz);
         }
+        if (ntiles) {
+            OSP_HIP(hipMemsetAsync(tile_status, 0, (uint64_t)ntiles * sizeof(uint64_t), s));
+            OSP_HIP(hipMemsetAsync(ticket, 0, sizeof(uint32_t), s));
+            tm.begin(PH_MERGE_K);
+            if (kMergeByRuns)
+                merge_runs_kernel<T, kRunsThreads><<<ntiles, kRunsThreads, 0, s>>>(
+                    tile_rows, ntiles, r1, d_row_off, base, d_arow, d_chunk_start, pcol, pval, heavy_nnz, tile_status,
+                    ticket, out_nnz + p, res->rowptr, c_col, c_val, out_nnz + p + 1);
+            else
+                merge_tiles_kernel<T, kMergeThreads><<<ntiles, kMergeThreads, 0, s>>>(
+                    tile_rows, ntiles, r1, d_row_off, base, colbits, pcol, pval, heavy_nnz, tile_status, ticket,
+                    out_nnz + p, res->rowptr, c_col, c_val, out_nnz + p + 1);
+            tm.end(PH_MERGE_K);
+            res->info.merge_launches++;
+        }
+        if (nheavy)
+            heavy_copy_kernel<T><<<nheavy, 256, 0, s>>>(heavy_rows, nheavy, d_row_off, base, heavy_nnz, res->rowptr, pcol,
+                                                        pval, c_col, c_val);
         tm.end(PH_MERGE);
-        // ---- compaction into the final CSR ----
-        tm.begin(PH_COMPACT);
-        device_exclusive_scan<LoadRowNnz, uint64_t>(LoadRowNnz{row_nnz, r0}, nr, c_local, scan_tmp, s);
-        const uint64_t nnz_panel = d2h(c_local + nr, s);
-        Piece pc{nullptr, nullptr, nnz_panel};
-        pc.col = (uint32_t *)ctx->alloc(std::max<uint64_t>(nnz_panel, 1) * sizeof(uint32_t));
-        pc.val = (T *)ctx->alloc(std::max<uint64_t>(nnz_panel, 1) * sizeof(T));
-        pieces.push_back(pc);
-        if (nnz_panel)
-            compact_rows_kernel<T><<<grid_for((nnz_panel + 7) / 8, 256), 256, 0, s>>>(c_local, r0, nr, row_src, pcol,
-                                                                                     pval, nnz_panel, pc.col, pc.val);
-        rowptr_finalize_kernel<<<grid_for(nr + 1, 256), 256, 0, s>>>(c_local, nr, nnz_total, res->rowptr + r0);
-        nnz_total += nnz_panel;
-        tm.end(PH_COMPACT);
     }
+    const uint64_t nnz_total = d2h(out_nnz + npanels, s);
     res->info.nnz_c = nnz_total;
-    if (pieces.size() == 1) {
-        res->colidx = pieces[0].col;
-        res->vals = pieces[0].val;
-    } else {
-        OSP_HIP(hipStreamSynchronize(s));
-        sc.drop(pcol);
-        sc.drop(pval);
-        res->colidx = (uint32_t *)ctx->alloc(std::max<uint64_t>(nnz_total, 1) * sizeof(uint32_t));
-        res->vals = ctx->alloc(std::max<uint64_t>(nnz_total, 1) * sizeof(T));
-        uint64_t o = 0;
-        for (auto &pc : pieces) {
-            if (pc.nnz) {
-                OSP_HIP(hipMemcpyAsync(res->colidx + o, pc.col, pc.nnz * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-                OSP_HIP(hipMemcpyAsync((T *)res->vals + o, pc.val, pc.nnz * sizeof(T), hipMemcpyDeviceToDevice, s));
-            }
-            o += pc.nnz;
+    // give memory back when the product compressed a lot (copy is small next to the P-sized work)
+    if (Context::bucket(std::max<uint64_t>(nnz_total, 1) * sizeof(T)) * 10 < Context::bucket(std::max<uint64_t>(cap_c, 1) * sizeof(T)) * 7) {
+        tm.begin(PH_COMPACT);
+        uint32_t *nc = (uint32_t *)ctx->alloc(std::max<uint64_t>(nnz_total, 1) * sizeof(uint32_t));
+        T *nv = (T *)ctx->alloc(std::max<uint64_t>(nnz_total, 1) * sizeof(T));
+        if (nnz_total) {
+            OSP_HIP(hipMemcpyAsync(nc, c_col, nnz_total * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+            OSP_HIP(hipMemcpyAsync(nv, c_val, nnz_total * sizeof(T), hipMemcpyDeviceToDevice, s));
         }
-        OSP_HIP(hipStreamSynchronize(s));
-        for (auto &pc : pieces) { ctx->release(pc.col); ctx->release(pc.val); }
+        ctx->release(res->colidx);
+        ctx->release(res->vals);
+        res->colidx = nc;
+        res->vals = nv;
+        tm.end(PH_COMPACT);
     }
 }
 
@@ -435,10 +445,14 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     // ---- symbolic: chunk offsets in (row, k) order ----
     tm.begin(PH_SYM);
     uint64_t *row_off = sc.get<uint64_t>(M + 1);
+    uint32_t *arow = sc.get<uint32_t>(M + 1);
     uint64_t *chunk_off = sc.get<uint64_t>(nnz);
+    uint64_t *chunk_start = sc.get<uint64_t>(nnz + 1);  // non-empty chunks, (row, k) order
     uint64_t P = 0;
     if (nnz == 0) {
         OSP_HIP(hipMemsetAsync(row_off, 0, (M + 1) * sizeof(uint64_t), s));
+        OSP_HIP(hipMemsetAsync(arow, 0, (M + 1) * sizeof(uint32_t), s));
+        OSP_HIP(hipMemsetAsync(chunk_start, 0, sizeof(uint64_t), s));
     } else {
         Scratch ss(ctx);
         uint32_t *keys[2] = {ss.get<uint32_t>(nnz), ss.get<uint32_t>(nnz)};
@@ -447,13 +461,21 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         uint32_t *hist = ss.get<uint32_t>(sort_hist_entries(nnz));
         uint32_t *hist_tmp = ss.get<uint32_t>(scan_scratch_entries(sort_hist_entries(nnz)));
         uint64_t *offs_sorted = ss.get<uint64_t>(nnz + 1);
+        uint32_t *ne_scan = ss.get<uint32_t>(nnz + 1);
         uint64_t *scan_tmp = ss.get<uint64_t>(scan_scratch_entries(nnz));
         sym_expand_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(a_colptr, a_rowidx, b_rowptr, k0, k1, e0, nnz, keys[0],
                                                              perm[0], w);
         const int cur = device_radix_sort_pairs<uint32_t>(keys, perm, nnz, std::max(1, bits_for(M)), hist, hist_tmp, s);
         device_exclusive_scan<LoadGatherW, uint64_t>(LoadGatherW{w, perm[cur]}, nnz, offs_sorted, scan_tmp, s);
+        if (kMergeByRuns) {
+            const NonEmptyFlag<LenGatherW> nef{LenGatherW{w, perm[cur]}};
+            device_exclusive_scan<NonEmptyFlag<LenGatherW>, uint32_t>(nef, nnz, ne_scan, (uint32_t *)scan_tmp, s);
+            chunk_compact_kernel<LenGatherW><<<grid_for(nnz + 1, 256), 256, 0, s>>>(LenGatherW{w, perm[cur]}, offs_sorted,
+                                                                                    ne_scan, nnz, chunk_start);
+        }
         sym_scatter_offsets_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(perm[cur], offs_sorted, nnz, chunk_off);
-        sym_row_offsets_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(keys[cur], offs_sorted, nnz, M, row_off);
+        sym_row_offsets_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(keys[cur], offs_sorted, kMergeByRuns ? ne_scan : nullptr,
+                                                                    nnz, M, row_off, arow);
         P = d2h(offs_sorted + nnz, s);
     }
     tm.end(PH_SYM);
@@ -469,7 +491,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     prod.prod = sc.get<uint64_t>(nk); prod.prod_off = sc.get<uint64_t>(nk + 1);
     prod.scan_tmp = sc.get<uint64_t>(scan_scratch_entries(nk));
 
-    merge_pipeline<T>(ctx, res, prod, M, N, row_off, P, cfg.partial_capacity, tm);
+    merge_pipeline<T>(ctx, res, prod, M, N, row_off, arow, chunk_start, P, cfg.partial_capacity, tm);
 
     OSP_HIP(hipEventRecord(ev1, s));
     OSP_HIP(hipStreamSynchronize(s));
@@ -517,16 +539,28 @@ static void merge_parts_impl(Context *ctx, Result *res, uint64_t M, uint64_t N, 
     OSP_HIP(hipMemcpyAsync(d_ci, ci.data(), nparts * sizeof(void *), hipMemcpyHostToDevice, s));
     OSP_HIP(hipMemcpyAsync(d_va, va.data(), nparts * sizeof(void *), hipMemcpyHostToDevice, s));
     tm.begin(PH_SYM);
+    const uint64_t ncand = M * (uint64_t)nparts;  // candidate chunk (r, p) = row r of part p
     uint64_t *row_off = sc.get<uint64_t>(M + 1);
-    uint64_t *scan_tmp = sc.get<uint64_t>(scan_scratch_entries(M));
-    device_exclusive_scan<PartsRowLen, uint64_t>(PartsRowLen{d_rp, nparts}, M, row_off, scan_tmp, s);
-    const uint64_t P = d2h(row_off + M, s);
+    uint32_t *arow = sc.get<uint32_t>(M + 1);
+    uint64_t *offs = sc.get<uint64_t>(ncand + 1);
+    uint32_t *ne_scan = sc.get<uint32_t>(ncand + 1);
+    uint64_t *chunk_start = sc.get<uint64_t>(ncand + 1);
+    uint64_t *scan_tmp = sc.get<uint64_t>(scan_scratch_entries(ncand));
+    const PartsChunkLen plen{d_rp, nparts};
+    device_exclusive_scan<PartsChunkLen, uint64_t>(plen, ncand, offs, scan_tmp, s);
+    if (kMergeByRuns) {
+        device_exclusive_scan<NonEmptyFlag<PartsChunkLen>, uint32_t>(NonEmptyFlag<PartsChunkLen>{plen}, ncand, ne_scan,
+                                                                     (uint32_t *)scan_tmp, s);
+        chunk_compact_kernel<PartsChunkLen><<<grid_for(ncand + 1, 256), 256, 0, s>>>(plen, offs, ne_scan, ncand, chunk_start);
+    }
+    parts_rows_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(offs, kMergeByRuns ? ne_scan : nullptr, nparts, M, row_off, arow);
+    const uint64_t P = d2h(offs + ncand, s);
     tm.end(PH_SYM);
     res->info.partials = P;
     PartsProducer<T> prod;
     prod.ctx = ctx; prod.d_rowptrs = d_rp; prod.d_colidxs = d_ci; prod.d_valss = d_va;
     prod.nparts = nparts; prod.row_off = row_off;
-    merge_pipeline<T>(ctx, res, prod, M, N, row_off, P, cfg.partial_capacity, tm);
+    merge_pipeline<T>(ctx, res, prod, M, N, row_off, arow, chunk_start, P, cfg.partial_capacity, tm);
     OSP_HIP(hipEventRecord(ev1, s));
     OSP_HIP(hipStreamSynchronize(s));
     float ms = 0;

@@ -19,11 +19,12 @@ namespace osp {
 // ---- tunables --------------------------------------------------------------------------------
 // partial products one LDS merge tile holds: sized so that two workgroups fit the CU's 160 KiB LDS
 template <class T> struct TileCap;
-template <> struct TileCap<float> { static constexpr int value = 4096; };
+template <> struct TileCap<float> { static constexpr int value = 3584; };
 template <> struct TileCap<double> { static constexpr int value = 3072; };
 constexpr int kTileMaxRows = 256;  // rows per tile (bounds the row bits of the sort key)
-constexpr int kMergeThreads = 256;
+constexpr int kMergeThreads = 512;
 constexpr int kMulThreads = 256;
+constexpr bool kMergeByRuns = false;  // see merge_pipeline() in osp_api.hip
 constexpr int kMulPerWave = 2048;  // partial products per wave slice
 constexpr int kMulPerBlock = kMulPerWave * (kMulThreads / kWave);
 
@@ -103,14 +104,22 @@ __global__ void sym_scatter_offsets_kernel(const uint32_t *perm, const uint64_t 
     if (t < nnz) chunk_off[perm[t]] = offs_sorted[t];
 }
 
-// row_off[i] = staging offset of row i's first partial product, i in [0, M]
+// row_off[i] = staging offset of row i's first partial product, arow[i] = index of its first
+// non-empty chunk, i in [0, M]
 __global__ void sym_row_offsets_kernel(const uint32_t *rows_sorted, const uint64_t *offs_sorted,
-                                       uint64_t nnz, uint64_t M, uint64_t *row_off) {
+                                       const uint32_t *nonempty_scan, uint64_t nnz, uint64_t M,
+                                       uint64_t *row_off, uint32_t *arow) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > M) return;
     uint64_t t = lower_bound_dev(rows_sorted, 0, nnz, (uint64_t)i);
     row_off[i] = offs_sorted[t];  // offs_sorted has nnz+1 entries, [nnz] = P
+    if (nonempty_scan) arow[i] = nonempty_scan[t];
 }
+struct LenGatherW {  // chunk length of the t-th A entry in (row, k) order
+    const uint32_t *w;
+    const uint32_t *perm;
+    __device__ uint32_t operator()(uint64_t t) const { return w[perm[t]]; }
+};
 
 // ---- per-panel column windows ------------------------------------------------------------------
 // Panel = output rows [r0,r1).  For column k: the sub-column of A whose rows fall in the panel
@@ -250,92 +259,187 @@ __global__ void compact_flagged_kernel(F f, const uint32_t *scan, uint64_t n, ui
 
 // ---- merge: LDS tile ---------------------------------------------------------------------------
 // Reference: deduplicateCOO, SimSpGEMM.cpp:519-535 (sort by (row,col), sum equal keys, keep
-// zeros).  One workgroup per tile.  The merged rows are written back over the tile's own span
-// (it was fully staged into LDS first) and row_nnz / row_src record where each row now lives.
-template <class T>
+// zeros).  One workgroup per tile; tiles are handed out in output order by a ticket counter and a
+// decoupled look-back over `tile_status` gives every tile its offset in the final CSR, so merged
+// rows are written ONCE, straight to c_col / c_val / c_rowptr (no per-row compaction pass).
+constexpr uint64_t kStatusAgg = 1ull << 62, kStatusPrefix = 2ull << 62, kStatusMask = (1ull << 62) - 1;
+
+constexpr int kDigitBits = 9;                 // radix of one LDS sort pass
+constexpr int kDigits = 1 << kDigitBits;      // 512 buckets
+
+template <class T, int NT>
 struct MergeSmem {
     static constexpr int kTileCap = TileCap<T>::value;
     uint32_t key[2][kTileCap];
     uint16_t pos[2][kTileCap];
     uint16_t rank[kTileCap + 1];
     T val[kTileCap];
-    uint32_t cnt[kMergeThreads / kWave][kRadix];
+    uint16_t cnt[NT / kWave][kDigits];
     uint32_t rowo[kTileMaxRows + 1];
-    uint32_t scratch[kMergeThreads / kWave + 1];
+    uint32_t scratch[NT / kWave + 1];
+    uint32_t tile;
+    uint64_t excl;
 };
 
-template <class T>
-__global__ __launch_bounds__(kMergeThreads) void merge_tiles_kernel(
+// Rank of this lane among the lanes of its wave that hold the same digit (lower lanes first), and
+// the size of that group.  kDigitBits ballots; per bit one sign mask, one xnor and one and per half.
+__device__ __forceinline__ void wave_match_digit(unsigned digit, bool valid, unsigned &rank, unsigned &count) {
+    const uint64_t vm = __ballot(valid);
+    uint32_t plo = (uint32_t)vm, phi = (uint32_t)(vm >> 32);
+#pragma unroll
+    for (int b = 0; b < kDigitBits; b++) {
+        const uint32_t bit = (digit >> b) & 1u;
+        const uint64_t m = __ballot(bit != 0);
+        const uint32_t sbm = 0u - bit;  // all ones where my bit is set
+        plo &= ~((uint32_t)m ^ sbm);
+        phi &= ~((uint32_t)(m >> 32) ^ sbm);
+    }
+    rank = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+    count = __popc(plo) + __popc(phi);
+}
+
+// Exclusive prefix of tile `t` by decoupled look-back (called by wave 0 of the block).
+__device__ __forceinline__ uint64_t lookback_prefix(uint64_t *status, uint32_t t, uint64_t total) {
+    const unsigned lane = lane_id();
+    if (lane == 0)
+        __hip_atomic_store(&status[t], (t == 0 ? kStatusPrefix : kStatusAgg) | total, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t excl = 0;
+    int64_t b = (int64_t)t - 1;
+    while (b >= 0) {
+        const int64_t idx = b - (int64_t)lane;
+        uint64_t sv = kStatusPrefix;  // virtual tiles before 0: prefix 0
+        if (idx >= 0) sv = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t m_prefix = __ballot((sv >> 62) == 2), m_empty = __ballot((sv >> 62) == 0);
+        const int p = m_prefix ? __builtin_ctzll(m_prefix) : 64;  // nearest predecessor holding a prefix
+        const uint64_t need = p >= 63 ? ~0ull : ((2ull << p) - 1ull);
+        if (m_empty & need) { __builtin_amdgcn_s_sleep(2); continue; }  // someone nearer has not published yet
+        uint64_t v = ((int)lane <= p) ? (sv & kStatusMask) : 0ull;
+        excl += wave_reduce_sum(v);
+        if (p < 64) break;
+        b -= kWave;
+    }
+    if (lane == 0 && t != 0)
+        __hip_atomic_store(&status[t], kStatusPrefix | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
+// ABL: ablation switches for tools/bench_merge.hip only (1 = no sort, 2 = no look-back, 4 = no ticket);
+// the library always instantiates ABL = 0.
+template <class T, int NT, int ABL = 0>
+__global__ __launch_bounds__(NT) void merge_tiles_kernel(
     const uint32_t *__restrict__ tile_rows, uint32_t ntiles, uint64_t r_end,
-    const uint64_t *__restrict__ row_off, uint64_t base, int colbits, uint32_t *pcol, T *pval,
-    uint32_t *__restrict__ row_nnz, uint64_t *__restrict__ row_src) {
-    __shared__ MergeSmem<T> sm;
+    const uint64_t *__restrict__ row_off, uint64_t base, int colbits, const uint32_t *__restrict__ pcol,
+    const T *__restrict__ pval, const uint32_t *__restrict__ heavy_nnz, uint64_t *tile_status,
+    uint32_t *ticket, const uint64_t *__restrict__ out_base_p, int64_t *__restrict__ c_rowptr,
+    uint32_t *__restrict__ c_col, T *__restrict__ c_val, uint64_t *__restrict__ out_end_p) {
+    __shared__ MergeSmem<T, NT> sm;
     constexpr int kTileCap = TileCap<T>::value;
-    constexpr int NW = kMergeThreads / kWave;
+    constexpr int NW = NT / kWave;
     const unsigned tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
-    const uint32_t t = blockIdx.x;
+    if (tid == 0) sm.tile = (ABL & 4) ? blockIdx.x : atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t t = sm.tile;
+    if (t >= ntiles) return;
+    const uint64_t out_base = *out_base_p;
     const uint64_t ra = tile_rows[t];
     const uint64_t rb = (t + 1 < ntiles) ? (uint64_t)tile_rows[t + 1] : r_end;
     const uint32_t nr = (uint32_t)(rb - ra);
     const uint64_t s = row_off[ra] - base;
-    const uint32_t n64 = (uint32_t)min(row_off[rb] - base - s, (uint64_t)kTileCap + 1);
-    if (n64 > (uint32_t)kTileCap) return;  // a single long row: global-sort path
-    const uint32_t n = n64;
-    for (uint32_t r = tid; r <= nr; r += kMergeThreads) sm.rowo[r] = (uint32_t)(row_off[ra + r] - base - s);
-    __syncthreads();
-    if (n == 0) {
-        for (uint32_t r = tid; r < nr; r += kMergeThreads) { row_nnz[ra + r] = 0; row_src[ra + r] = s; }
+    const uint32_t n = (uint32_t)min(row_off[rb] - base - s, (uint64_t)kTileCap + 1);
+    if (n > (uint32_t)kTileCap) {
+        // a single long row, already reduced in place by the global-sort path: only take part in the
+        // offset chain; heavy_copy_kernel moves its entries once c_rowptr is known
+        if (w == 0) {
+            const uint64_t total = heavy_nnz[ra];
+            const uint64_t excl = lookback_prefix(tile_status, t, total);
+            if (lane == 0) {
+                c_rowptr[ra] = (int64_t)(out_base + excl);
+                if (t + 1 == ntiles) { c_rowptr[r_end] = (int64_t)(out_base + excl + total); *out_end_p = out_base + excl + total; }
+            }
+        }
         return;
     }
-    // stage: key = (local row << colbits) | col, payload = staging position
-    for (uint32_t i = tid; i < n; i += kMergeThreads) {
-        uint32_t lo = 0, hi = nr;  // last r with rowo[r] <= i
-        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (sm.rowo[mid] <= i) lo = mid; else hi = mid; }
-        sm.key[0][i] = (colbits < 32 ? (lo << colbits) : 0u) | pcol[s + i];
-        sm.pos[0][i] = (uint16_t)i;
-        sm.val[i] = pval[s + i];
+    for (uint32_t r = tid; r <= nr; r += NT) sm.rowo[r] = (uint32_t)(row_off[ra + r] - base - s);
+    __syncthreads();
+    // stage: key = (local row << colbits) | col, payload = staging position.  All global loads of a
+    // thread are issued before the first LDS write so that a wave keeps ~5 KB of HBM reads in flight.
+    {
+        constexpr int LPT = (kTileCap + NT - 1) / NT;
+        uint32_t lc[LPT];
+        T lv[LPT];
+#pragma unroll
+        for (int q = 0; q < LPT; q++) {
+            const uint32_t i = tid + q * NT;
+            lc[q] = 0; lv[q] = 0;
+            if (i < n) { lc[q] = pcol[s + i]; lv[q] = pval[s + i]; }
+        }
+#pragma unroll
+        for (int q = 0; q < LPT; q++) {
+            const uint32_t i = tid + q * NT;
+            if (i < n) {
+                uint32_t lo = 0, hi = nr;  // last r with rowo[r] <= i
+                while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (sm.rowo[mid] <= i) lo = mid; else hi = mid; }
+                sm.key[0][i] = (colbits < 32 ? (lo << colbits) : 0u) | lc[q];
+                sm.pos[0][i] = (uint16_t)i;
+                sm.val[i] = lv[q];
+            }
+        }
     }
     int rowbits = 0;
     while ((1u << rowbits) < nr) rowbits++;
-    const int nbits = colbits + rowbits;
-    // each wave ranks a contiguous quarter, so earlier waves = earlier positions (stable)
+    const int nbits = (n && !(ABL & 1)) ? colbits + rowbits : 0;
+    // each wave ranks a contiguous span, so earlier waves = earlier positions (stable)
+    constexpr int ITERS = (kTileCap / NW + kWave - 1) / kWave;  // wave iterations per pass
+    static_assert(NT >= kDigits, "one thread per digit in the scan step");
     const uint32_t per = (n + NW - 1) / NW;
     const uint32_t wbeg = min(w * per, n), wend = min(wbeg + per, n);
     int cur = 0;
     __syncthreads();
-    for (int shift = 0; shift < nbits; shift += 8) {
-        for (int d = lane; d < kRadix; d += kWave) sm.cnt[w][d] = 0;
-        // (a) rank inside the wave's span
-        for (uint32_t i0 = wbeg; i0 < wend; i0 += kWave) {
-            const uint32_t i = i0 + lane;
+    const int npass = (nbits + kDigitBits - 1) / kDigitBits;
+    const int pbits = npass ? (nbits + npass - 1) / npass : 0;  // balanced digit width (<= kDigitBits)
+    const uint32_t dmask = (1u << pbits) - 1u;
+    for (int pass = 0, shift = 0; pass < npass; pass++, shift += pbits) {
+        for (int d = lane; d < kDigits; d += kWave) sm.cnt[w][d] = 0;
+        // (a) rank inside the wave's span; keys and ranks stay in registers for (c)
+        uint32_t kreg[ITERS], rreg[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const uint32_t i = wbeg + it * kWave + lane;
             const bool valid = i < wend;
-            const unsigned d = valid ? (sm.key[cur][i] >> shift) & 255u : 0u;
-            const uint64_t peers = wave_match8(d, valid);
-            const unsigned rk = __popcll(peers & lanemask_lt());
+            kreg[it] = valid ? sm.key[cur][i] : 0u;
+            const unsigned d = (kreg[it] >> shift) & dmask;
+            unsigned rk, cntd;
+            wave_match_digit(d, valid, rk, cntd);
             if (valid) {
                 const uint32_t c = sm.cnt[w][d];
-                sm.rank[i] = (uint16_t)(c + rk);
-                if (rk == 0) sm.cnt[w][d] = c + (uint32_t)__popcll(peers);
+                rreg[it] = c + rk;
+                if (rk == 0) sm.cnt[w][d] = (uint16_t)(c + cntd);
             }
         }
         __syncthreads();
-        // (b) exclusive scan over (digit major, wave minor)
+        // (b) exclusive scan over (digit major, wave minor); thread d owns digit d
         {
             uint32_t c[NW], ssum = 0;
+            if (tid < kDigits) {
 #pragma unroll
-            for (int ww = 0; ww < NW; ww++) { c[ww] = sm.cnt[ww][tid]; ssum += c[ww]; }
+                for (int ww = 0; ww < NW; ww++) { c[ww] = sm.cnt[ww][tid]; ssum += c[ww]; }
+            }
             uint32_t total;
-            uint32_t ex = block_excl_scan<uint32_t, kMergeThreads>(ssum, sm.scratch, &total);
+            uint32_t ex = block_excl_scan<uint32_t, NT>(ssum, sm.scratch, &total);
+            if (tid < kDigits) {
 #pragma unroll
-            for (int ww = 0; ww < NW; ww++) { sm.cnt[ww][tid] = ex; ex += c[ww]; }
+                for (int ww = 0; ww < NW; ww++) { sm.cnt[ww][tid] = (uint16_t)ex; ex += c[ww]; }
+            }
         }
         __syncthreads();
         // (c) scatter
-        for (uint32_t i0 = wbeg; i0 < wend; i0 += kWave) {
-            const uint32_t i = i0 + lane;
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const uint32_t i = wbeg + it * kWave + lane;
             if (i < wend) {
-                const uint32_t k = sm.key[cur][i];
-                const uint32_t dst = sm.cnt[w][(k >> shift) & 255u] + sm.rank[i];
+                const uint32_t k = kreg[it];
+                const uint32_t dst = (uint32_t)sm.cnt[w][(k >> shift) & dmask] + rreg[it];
                 sm.key[cur ^ 1][dst] = k;
                 sm.pos[cur ^ 1][dst] = sm.pos[cur][i];
             }
@@ -343,8 +447,8 @@ __global__ __launch_bounds__(kMergeThreads) void merge_tiles_kernel(
         cur ^= 1;
         __syncthreads();
     }
-    // head flags + exclusive scan (blocked: thread owns 16 consecutive sorted entries)
-    constexpr int IPT = kTileCap / kMergeThreads;
+    // head flags + exclusive scan (blocked: thread owns IPT consecutive sorted entries)
+    constexpr int IPT = (kTileCap + NT - 1) / NT;
     const uint32_t ib = tid * IPT;
     uint32_t heads = 0, hmask = 0;
 #pragma unroll
@@ -357,38 +461,53 @@ __global__ __launch_bounds__(kMergeThreads) void merge_tiles_kernel(
         }
     }
     uint32_t total;
-    uint32_t ex = block_excl_scan<uint32_t, kMergeThreads>(heads, sm.scratch, &total);
+    uint32_t ex = block_excl_scan<uint32_t, NT>(heads, sm.scratch, &total);
+    // the tile's unique count is known: start the look-back now, it overlaps the run sums below
+    if (w == 0) {
+        const uint64_t excl = (ABL & 2) ? (uint64_t)t * kTileCap : lookback_prefix(tile_status, t, total);
+        if (lane == 0) sm.excl = excl;
+    }
+    uint32_t oslot[IPT];
 #pragma unroll
     for (int q = 0; q < IPT; q++) {
         const uint32_t i = ib + q;
+        oslot[q] = ex;
         if (i < n) {
             sm.rank[i] = (uint16_t)ex;  // output slot of the run that starts at/behind i
             ex += (hmask >> q) & 1u;
         }
     }
     if (tid == 0) sm.rank[n] = (uint16_t)total;
-    __syncthreads();
-    // each head sums its run in staging order and writes the merged entry in place
+    // each head sums its run in staging order (= ascending k)
     const uint32_t colmask = colbits < 32 ? ((1u << colbits) - 1u) : 0xffffffffu;
+    T acc[IPT];
+    uint32_t ocol[IPT];
 #pragma unroll
     for (int q = 0; q < IPT; q++) {
         const uint32_t i = ib + q;
+        acc[q] = 0; ocol[q] = 0;
         if (i < n && ((hmask >> q) & 1u)) {
             const uint32_t k = sm.key[cur][i];
-            T acc = sm.val[sm.pos[cur][i]];
-            for (uint32_t u = i + 1; u < n && sm.key[cur][u] == k; u++) acc += sm.val[sm.pos[cur][u]];
-            const uint32_t o = sm.rank[i];
-            pcol[s + o] = k & colmask;
-            pval[s + o] = acc;
+            T a = sm.val[sm.pos[cur][i]];
+            for (uint32_t u = i + 1; u < n && sm.key[cur][u] == k; u++) a += sm.val[sm.pos[cur][u]];
+            acc[q] = a;
+            ocol[q] = k & colmask;
         }
     }
-    // rows keep their index span through the sort (row is the major key)
-    for (uint32_t r = tid; r < nr; r += kMergeThreads) {
-        const uint32_t x0 = sm.rowo[r], x1 = sm.rowo[r + 1];
-        const uint32_t o0 = sm.rank[x0], o1 = sm.rank[x1];
-        row_nnz[ra + r] = o1 - o0;
-        row_src[ra + r] = s + o0;
+    __syncthreads();  // all gathers from val[] / key[cur] done; look-back result published in sm.excl
+    // compact into LDS (val[] and the idle key buffer), then stream out with consecutive lanes on
+    // consecutive addresses
+#pragma unroll
+    for (int q = 0; q < IPT; q++) {
+        const uint32_t i = ib + q;
+        if (i < n && ((hmask >> q) & 1u)) { sm.key[cur ^ 1][oslot[q]] = ocol[q]; sm.val[oslot[q]] = acc[q]; }
     }
+    __syncthreads();
+    const uint64_t obase = out_base + sm.excl;
+    for (uint32_t o = tid; o < total; o += NT) { c_col[obase + o] = sm.key[cur ^ 1][o]; c_val[obase + o] = sm.val[o]; }
+    // rows keep their index span through the sort (row is the major key)
+    for (uint32_t r = tid; r < nr; r += NT) c_rowptr[ra + r] = (int64_t)(obase + sm.rank[sm.rowo[r]]);
+    if (t + 1 == ntiles && tid == 0) { c_rowptr[r_end] = (int64_t)(obase + total); *out_end_p = obase + total; }
 }
 
 // ---- merge: global-sort path for rows longer than kTileCap ---------------------------------------
@@ -435,63 +554,53 @@ __global__ void heavy_reduce_kernel(const uint64_t *key, const T *sorted_val, co
     pval[o] = acc;
 }
 __global__ void heavy_rows_kernel(const uint32_t *rows, const uint64_t *hoff, uint32_t nheavy,
-                                  const uint64_t *headscan, const uint64_t *row_off, uint64_t base,
-                                  uint32_t *row_nnz, uint64_t *row_src) {
+                                  const uint64_t *headscan, uint32_t *heavy_nnz) {
     uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= nheavy) return;
-    row_nnz[rows[h]] = (uint32_t)(headscan[hoff[h + 1]] - headscan[hoff[h]]);
-    row_src[rows[h]] = row_off[rows[h]] - base;
+    heavy_nnz[rows[h]] = (uint32_t)(headscan[hoff[h + 1]] - headscan[hoff[h]]);
 }
-
-// ---- compaction --------------------------------------------------------------------------------
-struct LoadRowNnz {
-    const uint32_t *row_nnz;
-    uint64_t r0;
-    __device__ uint64_t operator()(uint64_t t) const { return row_nnz[r0 + t]; }
-};
-// out[c_rowptr_local[r] + i] = staging[row_src[r] + i]; thread owns 8 consecutive outputs
+// after merge_tiles_kernel fixed c_rowptr: move each long row's merged entries to their place
 template <class T>
-__global__ __launch_bounds__(256) void compact_rows_kernel(
-    const uint64_t *__restrict__ c_local /* nr+1, exclusive scan of row_nnz */, uint64_t r0, uint64_t nr,
-    const uint64_t *__restrict__ row_src, const uint32_t *__restrict__ pcol, const T *__restrict__ pval,
-    uint64_t nnz, uint32_t *__restrict__ c_col, T *__restrict__ c_val) {
-    constexpr int IPT = 8;
-    const uint64_t o0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * IPT;
-    if (o0 >= nnz) return;
-    uint64_t r = upper_bound_dev(c_local, 0, nr + 1, o0) - 1;  // row containing output o0
-    uint64_t rend = c_local[r + 1];
-    uint64_t src = row_src[r0 + r] + (o0 - c_local[r]);
-#pragma unroll
-    for (int q = 0; q < IPT; q++) {
-        const uint64_t o = o0 + q;
-        if (o >= nnz) break;
-        while (o >= rend) {  // next non-empty row
-            r++;
-            rend = c_local[r + 1];
-            src = row_src[r0 + r];
-        }
-        c_col[o] = pcol[src];
-        c_val[o] = pval[src];
-        src++;
+__global__ void heavy_copy_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *row_off, uint64_t base,
+                                  const uint32_t *heavy_nnz, const int64_t *c_rowptr, const uint32_t *pcol,
+                                  const T *pval, uint32_t *c_col, T *c_val) {
+    const uint32_t h = blockIdx.x;  // one workgroup per long row
+    if (h >= nheavy) return;
+    const uint32_t row = rows[h];
+    const uint64_t n = heavy_nnz[row], src = row_off[row] - base, dst = (uint64_t)c_rowptr[row];
+    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        c_col[dst + i] = pcol[src + i];
+        c_val[dst + i] = pval[src + i];
     }
 }
-__global__ void rowptr_finalize_kernel(const uint64_t *c_local, uint64_t nr, uint64_t offset,
-                                       int64_t *c_rowptr /* + r0 */) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t <= nr) c_rowptr[t] = (int64_t)(c_local[t] + offset);
-}
+
+// ---- output bound -------------------------------------------------------------------------------
+// nnz(C) <= sum_i min(U_i, N): capacity of the final CSR arrays
+struct RowUpperBound {
+    const uint64_t *row_off;
+    uint64_t N;
+    __device__ uint64_t operator()(uint64_t r) const { return min(row_off[r + 1] - row_off[r], N); }
+};
+__global__ void set_u64_kernel(uint64_t *p, uint64_t v) { *p = v; }
 
 // ---- CSR parts -> staging (multi-GPU final merge) ----------------------------------
 // Row r of part p becomes one chunk of row r; chunks ordered by p.
-struct PartsRowLen {
+struct PartsChunkLen {  // candidate chunk c = r * nparts + p
     const int64_t *const *rowptrs;
     int nparts;
-    __device__ uint64_t operator()(uint64_t r) const {
-        uint64_t s = 0;
-        for (int p = 0; p < nparts; p++) s += (uint64_t)(rowptrs[p][r + 1] - rowptrs[p][r]);
-        return s;
+    __device__ uint64_t operator()(uint64_t c) const {
+        const uint64_t r = c / (uint64_t)nparts;
+        const int p = (int)(c - r * (uint64_t)nparts);
+        return (uint64_t)(rowptrs[p][r + 1] - rowptrs[p][r]);
     }
 };
+__global__ void parts_rows_kernel(const uint64_t *offs, const uint32_t *flscan, int nparts, uint64_t M,
+                                  uint64_t *row_off, uint32_t *arow) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > M) return;
+    row_off[r] = offs[r * (uint64_t)nparts];
+    if (flscan) arow[r] = flscan[r * (uint64_t)nparts];
+}
 template <class T>
 __global__ void parts_scatter_kernel(const int64_t *const *rowptrs, const uint32_t *const *colidxs,
                                      const T *const *valss, int nparts, uint64_t r0, uint64_t r1,

@@ -27,6 +27,22 @@ __device__ __forceinline__ T wave_incl_scan(T v) {
     }
     return v;
 }
+// 32-bit inclusive scan on the DPP path (no LDS crossbar): Hillis-Steele inside each row of 16
+// lanes (row_shr 1,2,4,8 with zero fill), then row_bcast:15 / row_bcast:31 to carry across rows.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_fetch(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+template <>
+__device__ __forceinline__ uint32_t wave_incl_scan<uint32_t>(uint32_t v) {
+    v += dpp_fetch<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_fetch<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_fetch<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_fetch<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_fetch<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3
+    v += dpp_fetch<0x143, 0xc>(v);  // row_bcast:31 -> rows 2 and 3
+    return v;
+}
 
 template <class T>
 __device__ __forceinline__ T wave_reduce_sum(T v) {
@@ -36,29 +52,24 @@ __device__ __forceinline__ T wave_reduce_sum(T v) {
 }
 
 // Exclusive scan across a block of NT threads (NT multiple of 64, <= 1024).  `scratch` holds
-// NT/64 + 1 entries of T.  Returns the exclusive prefix of `v`; *total gets the block sum.
+// NT/64 entries of T.  Returns the exclusive prefix of `v`; *total gets the block sum.
 template <class T, int NT>
 __device__ __forceinline__ T block_excl_scan(T v, T *scratch, T *total) {
     constexpr int NW = NT / kWave;
-    T incl = wave_incl_scan(v);
+    const T incl = wave_incl_scan(v);
     const int w = threadIdx.x >> 6;
     if (lane_id() == kWave - 1) scratch[w] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        T run = 0;
+    T off = 0, tot = 0;
 #pragma unroll
-        for (int i = 0; i < NW; i++) {
-            T t = scratch[i];
-            scratch[i] = run;
-            run += t;
-        }
-        scratch[NW] = run;
+    for (int i = 0; i < NW; i++) {
+        const T tv = scratch[i];
+        if (i < w) off += tv;
+        tot += tv;
     }
-    __syncthreads();
-    T res = incl - v + scratch[w];
-    *total = scratch[NW];
-    __syncthreads();
-    return res;
+    *total = tot;
+    __syncthreads();  // scratch may be reused by the caller's next scan
+    return incl - v + off;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1,0 +1,122 @@
+// tools/bench_merge.hip -- A/B timing of merge_tiles_kernel variants in ONE process (interleaved rounds).
+// Synthetic staging buffer: rows of `rowlen` partial products with random columns in [0, 2^22).
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I outerspace_amd/csrc tools/bench_merge.hip -o tools/bench_merge
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include "osp_kernels.h"
+#include "osp_merge_runs.h"
+using namespace osp;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__global__ void fill_kernel(uint32_t *pcol, double *pval, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t x = i * 0x9E3779B97F4A7C15ull; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    pcol[i] = (uint32_t)(x & ((1u << 22) - 1));
+    pval[i] = 1.0;
+}
+// chunks of `clen` entries, columns ascending inside a chunk, pseudo-random across chunks
+__global__ void fill_sorted_kernel(uint32_t *pcol, uint64_t n, uint32_t clen) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t c = i / clen, j = i % clen;
+    uint64_t x = c * 0x9E3779B97F4A7C15ull; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    const uint32_t stride = (1u << 22) / clen;
+    pcol[i] = (uint32_t)(x % stride) + (uint32_t)j * stride;
+}
+__global__ void chunks_kernel(uint64_t *chunk_start, uint64_t nchunks, uint32_t clen) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= nchunks) chunk_start[i] = i * clen;
+}
+__global__ void arow_kernel(uint32_t *arow, uint64_t M, uint32_t cpr) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= M) arow[i] = (uint32_t)(i * cpr);
+}
+uint32_t *g_arow; uint64_t *g_chunk_start;
+template <int NT, int ABL>
+float run_runs(uint32_t *tile_rows, uint32_t ntiles, uint64_t M, uint64_t *row_off, uint32_t *pcol, double *pval,
+          uint32_t *heavy, uint64_t *status, uint32_t *ticket, uint64_t *outn, int64_t *rowptr, uint32_t *ccol, double *cval) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipMemsetAsync(status, 0, (uint64_t)ntiles * 8, 0));
+    CK(hipMemsetAsync(ticket, 0, 4, 0));
+    CK(hipMemsetAsync(outn, 0, 16, 0));
+    CK(hipEventRecord(a, 0));
+    merge_runs_kernel<double, NT, ABL><<<ntiles, NT, 0, 0>>>(tile_rows, ntiles, M, row_off, 0, g_arow, g_chunk_start, pcol, pval, heavy,
+                                                             status, ticket, outn, rowptr, ccol, cval, outn + 1);
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
+    return ms;
+}
+__global__ void rows_kernel(uint64_t *row_off, uint64_t M, uint32_t rowlen) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= M) row_off[i] = i * rowlen;
+}
+__global__ void tiles_kernel(uint32_t *tile_rows, uint32_t ntiles, uint32_t rpt) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ntiles) tile_rows[i] = i * rpt;
+}
+
+template <int NT, int ABL>
+float run(uint32_t *tile_rows, uint32_t ntiles, uint64_t M, uint64_t *row_off, uint32_t *pcol, double *pval,
+          uint32_t *heavy, uint64_t *status, uint32_t *ticket, uint64_t *outn, int64_t *rowptr, uint32_t *ccol, double *cval) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipMemsetAsync(status, 0, (uint64_t)ntiles * 8, 0));
+    CK(hipMemsetAsync(ticket, 0, 4, 0));
+    CK(hipMemsetAsync(outn, 0, 16, 0));
+    CK(hipEventRecord(a, 0));
+    merge_tiles_kernel<double, NT, ABL><<<ntiles, NT, 0, 0>>>(tile_rows, ntiles, M, row_off, 0, 22, pcol, pval, heavy, status,
+                                                              ticket, outn, rowptr, ccol, cval, outn + 1);
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
+    return ms;
+}
+
+int main(int argc, char **argv) {
+    const uint32_t rowlen = argc > 1 ? atoi(argv[1]) : 256;
+    const uint32_t rpt = argc > 2 ? atoi(argv[2]) : 9;          // rows per tile
+    const uint64_t M = argc > 3 ? atoll(argv[3]) : (1u << 20);
+    const uint64_t P = M * rowlen;
+    const uint32_t ntiles = (uint32_t)((M + rpt - 1) / rpt);
+    uint32_t *pcol, *tile_rows, *heavy, *ticket, *ccol; double *pval, *cval; uint64_t *row_off, *status, *outn; int64_t *rowptr;
+    CK(hipMalloc(&pcol, P * 4)); CK(hipMalloc(&pval, P * 8)); CK(hipMalloc(&ccol, (P + 4096ull * 0) * 4 + (uint64_t)ntiles * 3072 * 4));
+    CK(hipMalloc(&cval, (uint64_t)ntiles * 3072 * 8 + P * 8)); CK(hipMalloc(&row_off, (M + 1) * 8)); CK(hipMalloc(&tile_rows, ntiles * 4));
+    CK(hipMalloc(&heavy, M * 4)); CK(hipMalloc(&status, (uint64_t)ntiles * 8)); CK(hipMalloc(&ticket, 4)); CK(hipMalloc(&outn, 16));
+    CK(hipMalloc(&rowptr, (M + 1) * 8));
+    const uint32_t clen = argc > 4 ? atoi(argv[4]) : 16;
+    fill_kernel<<<(unsigned)((P + 255) / 256), 256>>>(pcol, pval, P);
+    fill_sorted_kernel<<<(unsigned)((P + 255) / 256), 256>>>(pcol, P, clen);
+    CK(hipMalloc(&g_arow, (M + 1) * 4)); CK(hipMalloc(&g_chunk_start, (P / clen + 2) * 8));
+    chunks_kernel<<<(unsigned)((P / clen + 256) / 256), 256>>>(g_chunk_start, P / clen, clen);
+    arow_kernel<<<(unsigned)((M + 256) / 256), 256>>>(g_arow, M, rowlen / clen);
+    rows_kernel<<<(unsigned)((M + 256) / 256), 256>>>(row_off, M, rowlen);
+    tiles_kernel<<<(ntiles + 255) / 256, 256>>>(tile_rows, ntiles, rpt);
+    CK(hipDeviceSynchronize());
+    printf("P=%llu partials, %u tiles of %u rows x %u (%u per tile), algorithmic bytes %.2f GB\n", (unsigned long long)P, ntiles, rpt,
+           rowlen, rpt * rowlen, (12.0 * P * 2) / 1e9);
+#define ARGS tile_rows, ntiles, M, row_off, pcol, pval, heavy, status, ticket, outn, rowptr, ccol, cval
+    struct V { const char *name; float (*fn)(uint32_t *, uint32_t, uint64_t, uint64_t *, uint32_t *, double *, uint32_t *, uint64_t *, uint32_t *, uint64_t *, int64_t *, uint32_t *, double *); };
+    std::vector<V> vs = {
+        {"radix NT512 full", run<512, 0>}, {"radix NT1024 full", run<1024, 0>}, {"radix NT512 nosort", run<512, 1>},
+        {"runs NT512 full", run_runs<512, 0>}, {"runs NT256 full", run_runs<256, 0>}, {"runs NT1024 full", run_runs<1024, 0>},
+        {"runs NT512 nomerge", run_runs<512, 1>}, {"runs NT512 nolb+notick", run_runs<512, 6>},
+    };
+    std::vector<std::vector<float>> t(vs.size());
+    for (int round = 0; round < 5; round++)
+        for (size_t v = 0; v < vs.size(); v++) t[v].push_back(vs[v].fn(ARGS));
+    for (size_t v = 0; v < vs.size(); v++) {
+        std::sort(t[v].begin(), t[v].end());
+        printf("%-28s median %8.3f ms  min %8.3f ms   %7.1f GB/s (alg)\n", vs[v].name, t[v][2], t[v][0], 24.0 * P / (t[v][2] * 1e-3) / 1e9);
+    }
+    return 0;
+}
