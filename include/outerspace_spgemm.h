@@ -77,8 +77,10 @@ typedef struct osp_result_info {
     uint64_t partials;          /* P = sum_k nnz(A[:,k]) * nnz(B[k,:])  (reference mulflops_ref) */
     uint32_t panels;            /* output-row panels processed */
     uint64_t light_tiles;       /* merge tiles reduced in LDS */
-    uint64_t heavy_rows;        /* rows reduced by the global-sort path */
-    uint64_t heavy_partials;
+    uint64_t heavy_rows;        /* rows longer than one LDS tile: split by column range first */
+    uint64_t heavy_partials;    /* partial products in those rows */
+    uint64_t sorted_segments;   /* segments still too long after the split: global-sort path */
+    uint64_t sorted_partials;
     float ms_symbolic, ms_multiply, ms_merge, ms_compact, ms_total;   /* phases (all launches in them) */
     float ms_multiply_kernel, ms_merge_kernel;  /* multiply_kernel / merge_tiles_kernel launches alone */
     uint32_t multiply_launches, merge_launches; /* number of those launches */

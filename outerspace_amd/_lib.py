@@ -34,6 +34,7 @@ class ResultInfo(C.Structure):
                 ("nnz_a", C.c_uint64), ("nnz_b", C.c_uint64), ("nnz_c", C.c_uint64),
                 ("partials", C.c_uint64), ("panels", C.c_uint32), ("light_tiles", C.c_uint64),
                 ("heavy_rows", C.c_uint64), ("heavy_partials", C.c_uint64),
+                ("sorted_segments", C.c_uint64), ("sorted_partials", C.c_uint64),
                 ("ms_symbolic", C.c_float), ("ms_multiply", C.c_float), ("ms_merge", C.c_float),
                 ("ms_compact", C.c_float), ("ms_total", C.c_float),
                 ("ms_multiply_kernel", C.c_float), ("ms_merge_kernel", C.c_float),

@@ -18,6 +18,7 @@
 #include "osp_internal.h"
 #include "osp_kernels.h"
 #include "osp_merge_runs.h"
+#include "osp_split.h"
 
 namespace osp {
 
@@ -165,6 +166,133 @@ template <class T> struct Producer {
                          uint32_t *pcol, T *pval, PhaseTimer &tm) = 0;
 };
 
+// ---- rows of partial products -> merged rows -------------------------------------------------------
+// `rows` are real output rows (level 0) or the column-range segments of split long rows (level 1).
+template <class T> struct MergeIO {
+    uint32_t *pcol; T *pval;             // partial products of rows [r0,r1), addressed row_off[r] - base
+    const uint64_t *row_off; uint64_t r0, r1, base;
+    int64_t *c_rowptr; uint32_t *c_col; T *c_val;  // output (c_rowptr indexed by absolute row id)
+    const uint64_t *out_in; uint64_t *out_out;    // entries written before / after this call (device)
+};
+
+template <class T>
+static void merge_rows(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO<T> &io, int colbits, bool allow_split) {
+    hipStream_t s = ctx->stream;
+    Scratch sc(ctx);
+    constexpr uint32_t kCap = kMergeByRuns ? (uint32_t)RunCap<T>::value : (uint32_t)TileCap<T>::value;
+    const uint32_t max_rows = kMergeByRuns ? (uint32_t)kTileMaxRows
+                                           : (uint32_t)std::min<uint64_t>(kTileMaxRows, colbits >= 32 ? 1ull : (1ull << (32 - colbits)));
+    const uint64_t r0 = io.r0, r1 = io.r1, nr = r1 - r0, base = io.base;
+    uint32_t *flag_scan = sc.get<uint32_t>(nr + 1);
+    uint32_t *tile_rows = sc.get<uint32_t>(nr + 1);
+    uint32_t *heavy_rows = sc.get<uint32_t>(nr + 1);
+    uint32_t *heavy_nnz = sc.get<uint32_t>(nr + 1) - r0;  // indexed by absolute row id
+    uint64_t *scan_tmp = sc.get<uint64_t>(scan_scratch_entries(std::max<uint64_t>(nr + 1, 16)));
+    uint32_t *ticket = sc.get<uint32_t>(1);
+
+    TileStartFlag tsf{io.row_off, r0, r1, base, max_rows, kCap / 2};
+    device_exclusive_scan<TileStartFlag, uint32_t>(tsf, nr, flag_scan, (uint32_t *)scan_tmp, s);
+    compact_flagged_kernel<TileStartFlag><<<grid_for(nr, 256), 256, 0, s>>>(tsf, flag_scan, nr, r0, tile_rows);
+    const uint32_t ntiles = d2h(flag_scan + nr, s);
+    HeavyRowFlag hrf{io.row_off, r0, kCap};
+    device_exclusive_scan<HeavyRowFlag, uint32_t>(hrf, nr, flag_scan, (uint32_t *)scan_tmp, s);
+    compact_flagged_kernel<HeavyRowFlag><<<grid_for(nr, 256), 256, 0, s>>>(hrf, flag_scan, nr, r0, heavy_rows);
+    const uint32_t nheavy = d2h(flag_scan + nr, s);
+    if (allow_split) res->info.light_tiles += ntiles - nheavy;
+
+    Scratch hs(ctx);  // long-row buffers live until their entries have been copied into place
+    uint64_t *heavy_src = nullptr;
+    const uint32_t *hcopy_col = io.pcol;
+    const T *hcopy_val = io.pval;
+    if (nheavy) {
+        heavy_src = hs.get<uint64_t>(nheavy);
+        uint64_t *hoff = hs.get<uint64_t>((uint64_t)nheavy + 1);
+        uint64_t *hscan_tmp = hs.get<uint64_t>(scan_scratch_entries(nheavy));
+        device_exclusive_scan<HeavyLen, uint64_t>(HeavyLen{heavy_rows, io.row_off}, nheavy, hoff, hscan_tmp, s);
+        const uint64_t nh = d2h(hoff + nheavy, s);
+        if (nh >= 0xffffffffull) throw Error(OSP_ERR_CAPACITY, "long rows of one panel exceed 2^32 partial products");
+        if (allow_split) {
+            // ---- one stable split by column range, then the same tile merge on the segments ----
+            res->info.heavy_rows += nheavy;
+            res->info.heavy_partials += nh;
+            uint8_t *hbits = hs.get<uint8_t>(nheavy);
+            uint32_t *nstretch = hs.get<uint32_t>(nheavy), *nseg = hs.get<uint32_t>(nheavy);
+            uint64_t *nhist = hs.get<uint64_t>(nheavy);
+            uint64_t *blkbase = hs.get<uint64_t>((uint64_t)nheavy + 1), *vbase = hs.get<uint64_t>((uint64_t)nheavy + 1),
+                     *hbase = hs.get<uint64_t>((uint64_t)nheavy + 1);
+            split_params_kernel<<<grid_for(nheavy, 256), 256, 0, s>>>(heavy_rows, nheavy, io.row_off, colbits, hbits, nstretch,
+                                                                      nseg, nhist);
+            device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nstretch}, nheavy, blkbase, hscan_tmp, s);
+            device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nseg}, nheavy, vbase, hscan_tmp, s);
+            device_exclusive_scan<LoadU64, uint64_t>(LoadU64{nhist}, nheavy, hbase, hscan_tmp, s);
+            const uint64_t nblocks = d2h(blkbase + nheavy, s), nvirt = d2h(vbase + nheavy, s), ncell = d2h(hbase + nheavy, s);
+            if (ncell >= 0xffffffffull || nblocks >= 0x7fffffffull) throw Error(OSP_ERR_CAPACITY, "split histogram too large");
+            uint32_t *ghist = hs.get<uint32_t>(ncell + 1);
+            uint32_t *ghist_tmp = hs.get<uint32_t>(scan_scratch_entries(ncell + 1));
+            split_count_kernel<<<(unsigned)nblocks, kSplitThreads, 0, s>>>(heavy_rows, nheavy, blkbase, hbase, hbits, nstretch,
+                                                                         io.row_off, base, colbits, io.pcol, ghist);
+            device_exclusive_scan<LoadU32, uint32_t>(LoadU32{ghist}, ncell, ghist, ghist_tmp, s);
+            uint32_t *qcol = hs.get<uint32_t>(nh);
+            T *qval = hs.get<T>(nh);
+            split_scatter_kernel<T><<<(unsigned)nblocks, kSplitThreads, 0, s>>>(heavy_rows, nheavy, blkbase, hbase, hbits,
+                                                                              nstretch, io.row_off, base, colbits, io.pcol,
+                                                                              io.pval, ghist, qcol, qval);
+            uint64_t *vrow_off = hs.get<uint64_t>(nvirt + 1);
+            split_vrows_kernel<<<grid_for(nvirt + 1, 256), 256, 0, s>>>(nheavy, vbase, hbase, nstretch, ghist, nvirt, nh, vrow_off);
+            // merge the segments into a temporary CSR-like output
+            uint32_t *tcol = hs.get<uint32_t>(nh);
+            T *tval = hs.get<T>(nh);
+            int64_t *vptr = (int64_t *)hs.get<uint64_t>(nvirt + 1);
+            uint64_t *lvl_out = hs.get<uint64_t>(2);
+            OSP_HIP(hipMemsetAsync(lvl_out, 0, 2 * sizeof(uint64_t), s));
+            MergeIO<T> sub{qcol, qval, vrow_off, 0, nvirt, 0, vptr, tcol, tval, lvl_out, lvl_out + 1};
+            merge_rows<T>(ctx, res, tm, sub, colbits, false);
+            split_rows_done_kernel<<<grid_for(nheavy, 256), 256, 0, s>>>(heavy_rows, nheavy, vbase, vptr, heavy_nnz, heavy_src);
+            hcopy_col = tcol;
+            hcopy_val = tval;
+        } else {
+            // ---- segments that are still too long: global stable sort on (rank, col), run sums in place ----
+            res->info.sorted_segments += nheavy;
+            res->info.sorted_partials += nh;
+            uint64_t *keys[2] = {hs.get<uint64_t>(nh), hs.get<uint64_t>(nh)};
+            uint32_t *poss[2] = {hs.get<uint32_t>(nh), hs.get<uint32_t>(nh)};
+            uint32_t *hist = hs.get<uint32_t>(sort_hist_entries(nh));
+            uint32_t *hist_tmp = hs.get<uint32_t>(scan_scratch_entries(sort_hist_entries(nh)));
+            heavy_fill_kernel<<<grid_for(nh, 256), 256, 0, s>>>(heavy_rows, hoff, nheavy, io.row_off, base, colbits, io.pcol, nh,
+                                                                keys[0], poss[0]);
+            const int nbits = colbits + bits_for(nheavy);
+            const int cur = device_radix_sort_pairs<uint64_t>(keys, poss, nh, nbits, hist, hist_tmp, s);
+            T *sorted_val = hs.get<T>(nh);
+            heavy_gather_kernel<T><<<grid_for(nh, 256), 256, 0, s>>>(poss[cur], io.pval, nh, sorted_val);
+            uint64_t *headscan = hs.get<uint64_t>(nh + 1);
+            uint64_t *headscan_tmp = hs.get<uint64_t>(scan_scratch_entries(nh));
+            device_exclusive_scan<HeavyHeadFlag, uint64_t>(HeavyHeadFlag{keys[cur]}, nh, headscan, headscan_tmp, s);
+            heavy_reduce_kernel<T><<<grid_for(nh, 256), 256, 0, s>>>(keys[cur], sorted_val, headscan, nh, heavy_rows, hoff,
+                                                                     nheavy, io.row_off, base, colbits, io.pcol, io.pval);
+            heavy_rows_kernel<<<grid_for(nheavy, 256), 256, 0, s>>>(heavy_rows, hoff, nheavy, headscan, heavy_nnz);
+            heavy_src_inplace_kernel<<<grid_for(nheavy, 256), 256, 0, s>>>(heavy_rows, nheavy, io.row_off, base, heavy_src);
+        }
+    }
+    if (ntiles) {
+        uint64_t *tile_status = sc.get<uint64_t>(ntiles);
+        OSP_HIP(hipMemsetAsync(tile_status, 0, (uint64_t)ntiles * sizeof(uint64_t), s));
+        OSP_HIP(hipMemsetAsync(ticket, 0, sizeof(uint32_t), s));
+        tm.begin(PH_MERGE_K);
+        if (kMergeByRuns)
+            throw Error(OSP_ERR_ARG, "merge-by-runs build is only wired for bench_merge");
+        else
+            merge_tiles_kernel<T, kMergeThreads><<<ntiles, kMergeThreads, 0, s>>>(
+                tile_rows, ntiles, r1, io.row_off, base, colbits, io.pcol, io.pval, heavy_nnz, tile_status, ticket, io.out_in,
+                io.c_rowptr, io.c_col, io.c_val, io.out_out);
+        tm.end(PH_MERGE_K);
+        res->info.merge_launches++;
+    }
+    if (nheavy)
+        heavy_copy_kernel<T><<<nheavy * 8u, 256, 0, s>>>(heavy_rows, nheavy, heavy_src, heavy_nnz, io.c_rowptr, hcopy_col,
+                                                             hcopy_val, io.c_col, io.c_val);
+    OSP_HIP(hipGetLastError());  // a rejected launch must not pass silently
+}
+
 // ---- stages shared by both entry points: partial products of each row -> final CSR ----------------
 template <class T>
 static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_t M, uint64_t N,
@@ -175,10 +303,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     // merge algorithm of the LDS tiles: stable 9-bit LSD radix sort (default) or pairwise merging of the
     // pre-sorted chunks (osp_merge_runs.h).  Measured on MI355X with tools/bench_merge: radix 4.95 ms vs
     // runs 6.9 ms per 2.7e8 partial products (16 chunks of 16 per row), so radix is what ships.
-    constexpr uint32_t kCap = kMergeByRuns ? (uint32_t)RunCap<T>::value : (uint32_t)TileCap<T>::value;
     const int colbits = std::max(1, bits_for(N));
-    const uint32_t max_rows = kMergeByRuns ? (uint32_t)kTileMaxRows
-                                           : (uint32_t)std::min<uint64_t>(kTileMaxRows, colbits >= 32 ? 1ull : (1ull << (32 - colbits)));
 
     res->rowptr = (int64_t *)ctx->alloc((M + 1) * sizeof(int64_t));
     if (P == 0) {
@@ -228,14 +353,8 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     }
     uint32_t *pcol = sc.get<uint32_t>(max_panel);
     T *pval = sc.get<T>(max_panel);
-    uint32_t *heavy_nnz = sc.get<uint32_t>(M);
-    uint32_t *flag_scan = sc.get<uint32_t>(max_rows_panel + 1);
-    uint32_t *tile_rows = sc.get<uint32_t>(max_rows_panel + 1);
-    uint32_t *heavy_rows = sc.get<uint32_t>(max_rows_panel + 1);
-    uint64_t *tile_status = sc.get<uint64_t>(max_rows_panel + 1);
     uint64_t *scan_tmp = sc.get<uint64_t>(scan_scratch_entries(std::max<uint64_t>(M + 1, 16)));
     uint64_t *out_nnz = sc.get<uint64_t>((uint64_t)npanels + 1);  // nnz written before panel p
-    uint32_t *ticket = sc.get<uint32_t>(1);
     OSP_HIP(hipMemsetAsync(out_nnz, 0, sizeof(uint64_t), s));
 
     // final CSR arrays at an upper bound: nnz(C) <= sum_i min(U_i, N)
@@ -252,7 +371,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     T *c_val = (T *)res->vals;
 
     for (uint32_t p = 0; p < npanels; p++) {
-        const uint64_t r0 = bounds[p], r1 = bounds[p + 1], nr = r1 - r0;
+        const uint64_t r0 = bounds[p], r1 = bounds[p + 1];
         const uint64_t base = (npanels == 1) ? 0 : h_off[r0];
         const uint64_t count = (npanels == 1) ? P : h_off[r1] - base;
         // ---- multiply (or scatter of CSR parts) ----
@@ -261,59 +380,8 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         tm.end(PH_MUL);
         // ---- merge ----
         tm.begin(PH_MERGE);
-        TileStartFlag tsf{d_row_off, r0, r1, base, max_rows, kCap / 2};
-        device_exclusive_scan<TileStartFlag, uint32_t>(tsf, nr, flag_scan, (uint32_t *)scan_tmp, s);
-        compact_flagged_kernel<TileStartFlag><<<grid_for(nr, 256), 256, 0, s>>>(tsf, flag_scan, nr, r0, tile_rows);
-        const uint32_t ntiles = d2h(flag_scan + nr, s);
-        HeavyRowFlag hrf{d_row_off, r0, kCap};
-        device_exclusive_scan<HeavyRowFlag, uint32_t>(hrf, nr, flag_scan, (uint32_t *)scan_tmp, s);
-        compact_flagged_kernel<HeavyRowFlag><<<grid_for(nr, 256), 256, 0, s>>>(hrf, flag_scan, nr, r0, heavy_rows);
-        const uint32_t nheavy = d2h(flag_scan + nr, s);
-        res->info.light_tiles += ntiles - nheavy;
-        if (nheavy) {
-            // rows longer than one LDS tile: global stable sort on (row rank, col), run sums in place
-            Scratch hs(ctx);
-            uint64_t *hoff = hs.get<uint64_t>((uint64_t)nheavy + 1);
-            uint64_t *hscan_tmp = hs.get<uint64_t>(scan_scratch_entries(nheavy));
-            device_exclusive_scan<HeavyLen, uint64_t>(HeavyLen{heavy_rows, d_row_off}, nheavy, hoff, hscan_tmp, s);
-            const uint64_t nh = d2h(hoff + nheavy, s);
-            res->info.heavy_rows += nheavy;
-            res->info.heavy_partials += nh;
-            uint64_t *keys[2] = {hs.get<uint64_t>(nh), hs.get<uint64_t>(nh)};
-            uint32_t *poss[2] = {hs.get<uint32_t>(nh), hs.get<uint32_t>(nh)};
-            uint32_t *hist = hs.get<uint32_t>(sort_hist_entries(nh));
-            uint32_t *hist_tmp = hs.get<uint32_t>(scan_scratch_entries(sort_hist_entries(nh)));
-            heavy_fill_kernel<<<grid_for(nh, 256), 256, 0, s>>>(heavy_rows, hoff, nheavy, d_row_off, base, colbits,
-                                                                pcol, nh, keys[0], poss[0]);
-            const int nbits = colbits + bits_for(nheavy);
-            const int cur = device_radix_sort_pairs<uint64_t>(keys, poss, nh, nbits, hist, hist_tmp, s);
-            T *sorted_val = hs.get<T>(nh);
-            heavy_gather_kernel<T><<<grid_for(nh, 256), 256, 0, s>>>(poss[cur], pval, nh, sorted_val);
-            uint64_t *headscan = hs.get<uint64_t>(nh + 1);
-            uint64_t *headscan_tmp = hs.get<uint64_t>(scan_scratch_entries(nh));
-            device_exclusive_scan<HeavyHeadFlag, uint64_t>(HeavyHeadFlag{keys[cur]}, nh, headscan, headscan_tmp, s);
-            heavy_reduce_kernel<T><<<grid_for(nh, 256), 256, 0, s>>>(keys[cur], sorted_val, headscan, nh, heavy_rows,
-                                                                     hoff, nheavy, d_row_off, base, colbits, pcol, pval);
-            heavy_rows_kernel<<<grid_for(nheavy, 256), 256, 0, s>>>(heavy_rows, hoff, nheavy, headscan, heavy_nnz);
-        }
-        if (ntiles) {
-            OSP_HIP(hipMemsetAsync(tile_status, 0, (uint64_t)ntiles * sizeof(uint64_t), s));
-            OSP_HIP(hipMemsetAsync(ticket, 0, sizeof(uint32_t), s));
-            tm.begin(PH_MERGE_K);
-            if (kMergeByRuns)
-                merge_runs_kernel<T, kRunsThreads><<<ntiles, kRunsThreads, 0, s>>>(
-                    tile_rows, ntiles, r1, d_row_off, base, d_arow, d_chunk_start, pcol, pval, heavy_nnz, tile_status,
-                    ticket, out_nnz + p, res->rowptr, c_col, c_val, out_nnz + p + 1);
-            else
-                merge_tiles_kernel<T, kMergeThreads><<<ntiles, kMergeThreads, 0, s>>>(
-                    tile_rows, ntiles, r1, d_row_off, base, colbits, pcol, pval, heavy_nnz, tile_status, ticket,
-                    out_nnz + p, res->rowptr, c_col, c_val, out_nnz + p + 1);
-            tm.end(PH_MERGE_K);
-            res->info.merge_launches++;
-        }
-        if (nheavy)
-            heavy_copy_kernel<T><<<nheavy, 256, 0, s>>>(heavy_rows, nheavy, d_row_off, base, heavy_nnz, res->rowptr, pcol,
-                                                        pval, c_col, c_val);
+        MergeIO<T> io{pcol, pval, d_row_off, r0, r1, base, res->rowptr, c_col, c_val, out_nnz + p, out_nnz + p + 1};
+        merge_rows<T>(ctx, res, tm, io, colbits, true);
         tm.end(PH_MERGE);
     }
     const uint64_t nnz_total = d2h(out_nnz + npanels, s);

@@ -561,17 +561,22 @@ __global__ void heavy_rows_kernel(const uint32_t *rows, const uint64_t *hoff, ui
 }
 // after merge_tiles_kernel fixed c_rowptr: move each long row's merged entries to their place
 template <class T>
-__global__ void heavy_copy_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *row_off, uint64_t base,
-                                  const uint32_t *heavy_nnz, const int64_t *c_rowptr, const uint32_t *pcol,
-                                  const T *pval, uint32_t *c_col, T *c_val) {
-    const uint32_t h = blockIdx.x;  // one workgroup per long row
+__global__ void heavy_copy_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *heavy_src,
+                                  const uint32_t *heavy_nnz, const int64_t *c_rowptr, const uint32_t *scol,
+                                  const T *sval, uint32_t *c_col, T *c_val) {
+    const uint32_t h = blockIdx.x >> 3, sub = blockIdx.x & 7u;  // a long row is copied by 8 workgroups
     if (h >= nheavy) return;
     const uint32_t row = rows[h];
-    const uint64_t n = heavy_nnz[row], src = row_off[row] - base, dst = (uint64_t)c_rowptr[row];
-    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        c_col[dst + i] = pcol[src + i];
-        c_val[dst + i] = pval[src + i];
+    const uint64_t n = heavy_nnz[row], src = heavy_src[h], dst = (uint64_t)c_rowptr[row];
+    for (uint64_t i = (uint64_t)sub * blockDim.x + threadIdx.x; i < n; i += 8ull * blockDim.x) {
+        c_col[dst + i] = scol[src + i];
+        c_val[dst + i] = sval[src + i];
     }
+}
+__global__ void heavy_src_inplace_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *row_off, uint64_t base,
+                                         uint64_t *heavy_src) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < nheavy) heavy_src[h] = row_off[rows[h]] - base;
 }
 
 // ---- output bound -------------------------------------------------------------------------------

@@ -1,0 +1,179 @@
+// osp_split.h -- long rows: one stable MSD split by column range, so that the LDS tile kernel can
+// merge them too.
+//
+// A row whose partial products exceed one LDS tile (thousands of chunks' worth in skewed matrices)
+// is cut into 2^b column ranges ("segments"): one segmented, stable counting-sort pass on the top b
+// bits of the column moves its entries from the staging buffer into a second buffer, segment by
+// segment.  Inside a segment the staging order (ascending k) is preserved, so the merge still sums
+// equal keys in the oracle's order.  The segments then look like short rows: the ordinary tile
+// planner packs them and merge_tiles_kernel merges them; concatenated in segment order they are the
+// row's sorted result.  (Reference for the operation being implemented: deduplicateCOO,
+// SimSpGEMM.cpp:519-535.  The reference simply sorts everything; there is no counterpart of this
+// file.)
+#pragma once
+#include "osp_kernels.h"
+
+namespace osp {
+
+constexpr int kSplitThreads = 256;
+constexpr int kSplitStretch = 4096;   // entries of one long row handled by one workgroup
+constexpr int kSplitMaxBits = 12;     // at most 4096 segments per row
+constexpr int kSplitTarget = 256;     // aim for segments of about this many entries
+
+// per long row h: b = number of split bits, and the sizes that get scanned
+__global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *row_off, int colbits,
+                                    uint8_t *hbits, uint32_t *nstretch, uint32_t *nseg, uint64_t *nhist) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= nheavy) return;
+    const uint64_t U = row_off[rows[h] + 1] - row_off[rows[h]];
+    const uint64_t want = (U + kSplitTarget - 1) / kSplitTarget;
+    int b = 1;
+    while (b < kSplitMaxBits && (1ull << b) < want) b++;
+    b = min(b, colbits);
+    const uint32_t ns = (uint32_t)((U + kSplitStretch - 1) / kSplitStretch);
+    hbits[h] = (uint8_t)b;
+    nstretch[h] = ns;
+    nseg[h] = 1u << b;
+    nhist[h] = (uint64_t)ns << b;
+}
+struct LoadU32As64 {
+    const uint32_t *p;
+    __device__ uint64_t operator()(uint64_t i) const { return p[i]; }
+};
+
+// workgroup -> (long row h, stretch st)
+struct SplitJob {
+    uint32_t h, st, b, nst;
+    uint64_t beg, end;   // entry range in the staging buffer (panel-relative)
+    uint64_t hbase;      // first histogram cell of row h
+};
+__device__ __forceinline__ SplitJob split_job(const uint32_t *rows, uint32_t nheavy, const uint64_t *blkbase,
+                                              const uint64_t *hbase, const uint8_t *hbits, const uint32_t *nstretch,
+                                              const uint64_t *row_off, uint64_t base) {
+    SplitJob j;
+    j.h = (uint32_t)(upper_bound_dev(blkbase, 0, (uint64_t)nheavy + 1, (uint64_t)blockIdx.x) - 1);
+    j.st = (uint32_t)(blockIdx.x - blkbase[j.h]);
+    j.b = hbits[j.h];
+    j.nst = nstretch[j.h];
+    const uint64_t s = row_off[rows[j.h]] - base, e = row_off[rows[j.h] + 1] - base;
+    j.beg = s + (uint64_t)j.st * kSplitStretch;
+    j.end = min(j.beg + (uint64_t)kSplitStretch, e);
+    j.hbase = hbase[j.h];
+    return j;
+}
+
+// histogram of one stretch over the row's segments -> ghist[hbase + seg * nst + st]
+__global__ __launch_bounds__(kSplitThreads) void split_count_kernel(
+    const uint32_t *rows, uint32_t nheavy, const uint64_t *blkbase, const uint64_t *hbase, const uint8_t *hbits,
+    const uint32_t *nstretch, const uint64_t *row_off, uint64_t base, int colbits, const uint32_t *pcol, uint32_t *ghist) {
+    __shared__ uint32_t hist[1 << kSplitMaxBits];
+    const SplitJob j = split_job(rows, nheavy, blkbase, hbase, hbits, nstretch, row_off, base);
+    const uint32_t nseg = 1u << j.b;
+    for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) hist[d] = 0;
+    __syncthreads();
+    const int sh = colbits - (int)j.b;
+    for (uint64_t i = j.beg + threadIdx.x; i < j.end; i += kSplitThreads) atomicAdd(&hist[pcol[i] >> sh], 1u);
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) ghist[j.hbase + (uint64_t)d * j.nst + j.st] = hist[d];
+}
+
+// Lanes of this wave with the same `bits`-bit digit: rank among them (lower lanes first) and group size.
+__device__ __forceinline__ void wave_match_bits(unsigned digit, int bits, bool valid, unsigned &rank, unsigned &count) {
+    const uint64_t vm = __ballot(valid);
+    uint32_t plo = (uint32_t)vm, phi = (uint32_t)(vm >> 32);
+    for (int b = 0; b < bits; b++) {
+        const uint32_t bit = (digit >> b) & 1u;
+        const uint64_t m = __ballot(bit != 0);
+        const uint32_t sbm = 0u - bit;
+        plo &= ~((uint32_t)m ^ sbm);
+        phi &= ~((uint32_t)(m >> 32) ^ sbm);
+    }
+    rank = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+    count = __popc(plo) + __popc(phi);
+}
+
+// stable scatter of one stretch into the row's segments; goffs = exclusive scan of ghist
+template <class T>
+__global__ __launch_bounds__(kSplitThreads) void split_scatter_kernel(
+    const uint32_t *rows, uint32_t nheavy, const uint64_t *blkbase, const uint64_t *hbase, const uint8_t *hbits,
+    const uint32_t *nstretch, const uint64_t *row_off, uint64_t base, int colbits, const uint32_t *pcol,
+    const T *pval, const uint32_t *goffs, uint32_t *qcol, T *qval) {
+    constexpr int NW = kSplitThreads / kWave;
+    constexpr int ITERS = kSplitStretch / kSplitThreads;  // 16 wave iterations per wave span
+    __shared__ uint16_t cnt[NW][1 << kSplitMaxBits];
+    __shared__ uint32_t boff[1 << kSplitMaxBits];
+    const SplitJob j = split_job(rows, nheavy, blkbase, hbase, hbits, nstretch, row_off, base);
+    const uint32_t nseg = 1u << j.b;
+    const unsigned lane = lane_id(), w = threadIdx.x >> 6;
+    for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) {
+        boff[d] = goffs[j.hbase + (uint64_t)d * j.nst + j.st];
+#pragma unroll
+        for (int ww = 0; ww < NW; ww++) cnt[ww][d] = 0;
+    }
+    __syncthreads();
+    const int sh = colbits - (int)j.b;
+    // each wave owns a contiguous quarter of the stretch: earlier waves = earlier entries (stable)
+    const uint64_t wbeg = j.beg + (uint64_t)w * (kSplitStretch / NW);
+    uint32_t kc[ITERS], rk[ITERS];
+    T kv[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
+        const bool valid = i < j.end;
+        kc[it] = 0; kv[it] = 0;
+        if (valid) { kc[it] = pcol[i]; kv[it] = pval[i]; }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
+        const bool valid = i < j.end;
+        const unsigned d = kc[it] >> sh;
+        unsigned r, c;
+        wave_match_bits(d, (int)j.b, valid, r, c);
+        if (valid) {
+            const uint32_t cur = cnt[w][d];
+            rk[it] = cur + r;
+            if (r == 0) cnt[w][d] = (uint16_t)(cur + c);
+        }
+    }
+    __syncthreads();
+    // per segment: exclusive offsets of the waves, on top of the stretch's base
+    for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int ww = 0; ww < NW; ww++) { const uint32_t c = cnt[ww][d]; cnt[ww][d] = (uint16_t)run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
+        if (i < j.end) {
+            const unsigned d = kc[it] >> sh;
+            const uint32_t dst = boff[d] + cnt[w][d] + rk[it];
+            qcol[dst] = kc[it];
+            qval[dst] = kv[it];
+        }
+    }
+}
+
+// segment v of the split = "virtual row": its offset in the second buffer
+__global__ void split_vrows_kernel(uint32_t nheavy, const uint64_t *vbase, const uint64_t *hbase, const uint32_t *nstretch,
+                                   const uint32_t *goffs, uint64_t nvirt, uint64_t nh_total, uint64_t *vrow_off) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > nvirt) return;
+    if (v == nvirt) { vrow_off[v] = nh_total; return; }
+    const uint32_t h = (uint32_t)(upper_bound_dev(vbase, 0, (uint64_t)nheavy + 1, v) - 1);
+    const uint64_t d = v - vbase[h];
+    vrow_off[v] = goffs[hbase[h] + d * nstretch[h]];
+}
+// merged long row h: its entry count and where it sits in the temporary output
+__global__ void split_rows_done_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *vbase, const int64_t *vptr,
+                                       uint32_t *heavy_nnz, uint64_t *heavy_src) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= nheavy) return;
+    const int64_t a = vptr[vbase[h]], b = vptr[vbase[h + 1]];
+    heavy_nnz[rows[h]] = (uint32_t)(b - a);
+    heavy_src[h] = (uint64_t)a;
+}
+
+}  // namespace osp

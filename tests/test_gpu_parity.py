@@ -134,6 +134,34 @@ def test_rmat10_golden_digest(ctx, golden_dir, dt):
     assert res.info["heavy_rows"] > 0
 
 
+def test_long_rows_split_and_fallback(ctx, port):
+    """Rows far longer than an LDS tile: split by column range; a segment that is still too long
+    (one column hit by thousands of partial products) takes the global-sort path.  Bit-exact."""
+    rng = np.random.default_rng(3)
+    M, K, N = 8, 6000, 64
+    # row 0 of A is dense in k; every B row hits column 5 plus two random columns -> column 5 of C[0,:]
+    # collects K partial products (> one tile), the other columns a few hundred each
+    a_rows = np.concatenate([np.zeros(K, np.uint32), rng.integers(1, M, 400).astype(np.uint32)])
+    a_cols = np.concatenate([np.arange(K, dtype=np.uint32), rng.choice(K, 400, replace=False).astype(np.uint32)])
+    key = np.unique(a_rows.astype(np.int64) * K + a_cols)
+    a = ((key // K).astype(np.uint32), (key % K).astype(np.uint32), rng.uniform(0.5, 1.5, len(key)))
+    b_rows = np.repeat(np.arange(K, dtype=np.uint32), 3)
+    b_cols = np.stack([np.full(K, 5), rng.integers(6, 35, K), rng.integers(35, N, K)], 1).reshape(-1).astype(np.uint32)
+    b = (b_rows, b_cols, rng.uniform(0.5, 1.5, 3 * K))
+    for dt in (np.float64, np.float32):
+        got, want = run_both(ctx, port, M, K, N, a, b, dt)
+        assert got.info["heavy_rows"] >= 1 and got.info["sorted_segments"] >= 1
+        assert_same(got, want)
+
+
+def test_many_long_rows(ctx, port):
+    """More long rows than a 16-bit grid dimension holds, all split and merged bit-exactly."""
+    n, rows, cols, vals = gen.rmat_coo(17, 16, "mild", seed=2)
+    got, want = run_both(ctx, port, n, n, n, (rows, cols, vals), (rows, cols, vals), np.float64)
+    assert got.info["heavy_rows"] > 10000
+    assert_same(got, want)
+
+
 @pytest.mark.parametrize("preset,scale", [("uniform", 12), ("mild", 12), ("g500", 12)])
 def test_rmat_vs_oracle(ctx, port, preset, scale):
     n, rows, cols, vals = gen.rmat_coo(scale, 16, preset, seed=1)
