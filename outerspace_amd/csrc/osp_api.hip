@@ -50,6 +50,7 @@ struct Context {
     std::multimap<size_t, void *> free_list;
     std::map<void *, size_t> live;
     size_t pooled_bytes = 0;
+    uint32_t merge_grid = 512;  // persistent workgroups of merge_tiles_kernel (2 per CU fit the LDS)
 
     static size_t bucket(size_t bytes) {
         if (bytes < 4096) return 4096;
@@ -190,10 +191,17 @@ static void merge_rows(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO<
     uint64_t *scan_tmp = sc.get<uint64_t>(scan_scratch_entries(std::max<uint64_t>(nr + 1, 16)));
     uint32_t *ticket = sc.get<uint32_t>(1);
 
-    TileStartFlag tsf{io.row_off, r0, r1, base, max_rows, kCap / 2};
-    device_exclusive_scan<TileStartFlag, uint32_t>(tsf, nr, flag_scan, (uint32_t *)scan_tmp, s);
-    compact_flagged_kernel<TileStartFlag><<<grid_for(nr, 256), 256, 0, s>>>(tsf, flag_scan, nr, r0, tile_rows);
-    const uint32_t ntiles = d2h(flag_scan + nr, s);
+    // greedy tile packing: coarse blocks of ~8 tiles, one walker thread per block
+    CoarseStartFlag csf{io.row_off, r0, base, 8ull * kCap};
+    device_exclusive_scan<CoarseStartFlag, uint32_t>(csf, nr, flag_scan, (uint32_t *)scan_tmp, s);
+    compact_flagged_kernel<CoarseStartFlag><<<grid_for(nr, 256), 256, 0, s>>>(csf, flag_scan, nr, r0, heavy_rows /*tmp*/);
+    const uint32_t ncb = d2h(flag_scan + nr, s);
+    uint32_t *cb_rows = sc.get<uint32_t>(ncb), *cb_cnt = sc.get<uint32_t>((uint64_t)ncb + 1);
+    OSP_HIP(hipMemcpyAsync(cb_rows, heavy_rows, (uint64_t)ncb * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    tile_walk_kernel<<<grid_for(ncb, 128), 128, 0, s>>>(cb_rows, ncb, r1, io.row_off, kCap, max_rows, nullptr, cb_cnt, nullptr);
+    device_exclusive_scan<LoadU32, uint32_t>(LoadU32{cb_cnt}, ncb, cb_cnt, (uint32_t *)scan_tmp, s);
+    const uint32_t ntiles = d2h(cb_cnt + ncb, s);
+    tile_walk_kernel<<<grid_for(ncb, 128), 128, 0, s>>>(cb_rows, ncb, r1, io.row_off, kCap, max_rows, cb_cnt, nullptr, tile_rows);
     HeavyRowFlag hrf{io.row_off, r0, kCap};
     device_exclusive_scan<HeavyRowFlag, uint32_t>(hrf, nr, flag_scan, (uint32_t *)scan_tmp, s);
     compact_flagged_kernel<HeavyRowFlag><<<grid_for(nr, 256), 256, 0, s>>>(hrf, flag_scan, nr, r0, heavy_rows);
@@ -274,6 +282,8 @@ static void merge_rows(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO<
         }
     }
     if (ntiles) {
+        TileDesc *desc = (TileDesc *)sc.get<uint64_t>((uint64_t)ntiles * 3);
+        tile_desc_kernel<(int)kCap><<<grid_for(ntiles, 256), 256, 0, s>>>(tile_rows, ntiles, r1, io.row_off, base, desc);
         uint64_t *tile_status = sc.get<uint64_t>(ntiles);
         OSP_HIP(hipMemsetAsync(tile_status, 0, (uint64_t)ntiles * sizeof(uint64_t), s));
         OSP_HIP(hipMemsetAsync(ticket, 0, sizeof(uint32_t), s));
@@ -281,8 +291,8 @@ static void merge_rows(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO<
         if (kMergeByRuns)
             throw Error(OSP_ERR_ARG, "merge-by-runs build is only wired for bench_merge");
         else
-            merge_tiles_kernel<T, kMergeThreads><<<ntiles, kMergeThreads, 0, s>>>(
-                tile_rows, ntiles, r1, io.row_off, base, colbits, io.pcol, io.pval, heavy_nnz, tile_status, ticket, io.out_in,
+            merge_tiles_kernel<T, kMergeThreads><<<std::min<uint32_t>(ntiles, ctx->merge_grid), kMergeThreads, 0, s>>>(
+                desc, ntiles, r1, io.row_off, base, colbits, io.pcol, io.pval, heavy_nnz, tile_status, ticket, io.out_in,
                 io.c_rowptr, io.c_col, io.c_val, io.out_out);
         tm.end(PH_MERGE_K);
         res->info.merge_launches++;
@@ -706,6 +716,7 @@ static int context_create(int device, void *stream, bool own, osp_context_t *out
         throw Error(OSP_ERR_HIP, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     Context *c = new Context;
     c->device = device;
+    c->merge_grid = 2u * (uint32_t)prop.multiProcessorCount;
     if (own) { OSP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     else c->stream = (hipStream_t)stream;
     *out = (osp_context_t)c;

@@ -224,22 +224,39 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
 }
 
 // ---- tile planning -----------------------------------------------------------------------------
-// Row r of the panel starts a merge tile when its staging offset enters a new half-tile slot, when
-// it or its predecessor is longer than half a tile, or every kTileMaxRows rows.
-struct TileStartFlag {
+// Tiles are consecutive rows packed greedily up to the tile capacity (and kTileMaxRows rows); a row
+// longer than the capacity is a tile of its own.  Greedy packing is sequential, so the rows are first
+// cut into coarse blocks of ~8 tiles at fixed staging offsets; one thread walks each block.
+struct CoarseStartFlag {
     const uint64_t *row_off;
-    uint64_t r0, r1, base;
-    uint32_t max_rows;
-    uint32_t kTileHalf;  // half the tile capacity
+    uint64_t r0, base, slot;
     __device__ uint32_t operator()(uint64_t t) const {
-        const uint64_t r = r0 + t;
         if (t == 0) return 1;
-        const uint64_t o_prev = row_off[r - 1], o = row_off[r], o_next = row_off[r + 1];
-        const bool heavy = (o_next - o) > (uint64_t)kTileHalf, heavy_prev = (o - o_prev) > (uint64_t)kTileHalf;
-        const bool slot = ((o - base) / kTileHalf) != ((o_prev - base) / kTileHalf);
-        return (heavy || heavy_prev || slot || (t % max_rows) == 0) ? 1u : 0u;
+        const uint64_t r = r0 + t;
+        return ((row_off[r] - base) / slot != (row_off[r - 1] - base) / slot || (t & 0xffffu) == 0) ? 1u : 0u;
     }
 };
+// counts[j] = tiles of coarse block j (tile_rows == nullptr), or write them at tile_base[j]
+__global__ void tile_walk_kernel(const uint32_t *cb_rows, uint32_t ncb, uint64_t r_end, const uint64_t *row_off,
+                                 uint64_t cap, uint32_t max_rows, const uint32_t *tile_base, uint32_t *counts,
+                                 uint32_t *tile_rows) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ncb) return;
+    uint64_t r = cb_rows[j];
+    const uint64_t end = (j + 1 < ncb) ? (uint64_t)cb_rows[j + 1] : r_end;
+    uint32_t n = 0;
+    const uint32_t out = tile_rows ? tile_base[j] : 0u;
+    while (r < end) {
+        if (tile_rows) tile_rows[out + n] = (uint32_t)r;
+        const uint64_t lim = min(end, r + max_rows);
+        // last r2 in (r, lim] whose rows [r, r2) still fit
+        uint64_t r2 = upper_bound_dev(row_off, r + 1, lim + 1, row_off[r] + cap) - 1;
+        if (r2 <= r) r2 = r + 1;  // a row longer than a tile stands alone
+        r = r2;
+        n++;
+    }
+    if (!tile_rows) counts[j] = n;
+}
 struct HeavyRowFlag {
     const uint64_t *row_off;
     uint64_t r0;
@@ -299,6 +316,10 @@ __device__ __forceinline__ void wave_match_digit(unsigned digit, bool valid, uns
 }
 
 // Exclusive prefix of tile `t` by decoupled look-back (called by wave 0 of the block).
+// One round trip fetches kLookWin windows of 64 predecessors.  (Measured: wide windows lose -- the
+// extra polling traffic costs more than the walk saves -- so kLookWin = 1; what matters is that tiles
+// are ticketed in the order they will finish, see merge_tiles_kernel.)
+constexpr int kLookWin = 1;
 __device__ __forceinline__ uint64_t lookback_prefix(uint64_t *status, uint32_t t, uint64_t total) {
     const unsigned lane = lane_id();
     if (lane == 0)
@@ -307,207 +328,288 @@ __device__ __forceinline__ uint64_t lookback_prefix(uint64_t *status, uint32_t t
     uint64_t excl = 0;
     int64_t b = (int64_t)t - 1;
     while (b >= 0) {
-        const int64_t idx = b - (int64_t)lane;
-        uint64_t sv = kStatusPrefix;  // virtual tiles before 0: prefix 0
-        if (idx >= 0) sv = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint64_t m_prefix = __ballot((sv >> 62) == 2), m_empty = __ballot((sv >> 62) == 0);
-        const int p = m_prefix ? __builtin_ctzll(m_prefix) : 64;  // nearest predecessor holding a prefix
-        const uint64_t need = p >= 63 ? ~0ull : ((2ull << p) - 1ull);
-        if (m_empty & need) { __builtin_amdgcn_s_sleep(2); continue; }  // someone nearer has not published yet
-        uint64_t v = ((int)lane <= p) ? (sv & kStatusMask) : 0ull;
-        excl += wave_reduce_sum(v);
-        if (p < 64) break;
-        b -= kWave;
+        uint64_t sv[kLookWin];
+#pragma unroll
+        for (int j = 0; j < kLookWin; j++) {
+            const int64_t idx = b - (int64_t)(j * kWave) - (int64_t)lane;
+            sv[j] = kStatusPrefix;  // virtual tiles before 0: prefix 0
+            if (idx >= 0) sv[j] = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bool done = false, retry = false;
+        uint64_t part = 0;
+#pragma unroll
+        for (int j = 0; j < kLookWin; j++) {
+            if (!done && !retry) {
+                const uint64_t m_prefix = __ballot((sv[j] >> 62) == 2), m_empty = __ballot((sv[j] >> 62) == 0);
+                const int p = m_prefix ? __builtin_ctzll(m_prefix) : 64;  // nearest predecessor holding a prefix
+                const uint64_t need = p >= 63 ? ~0ull : ((2ull << p) - 1ull);
+                if (m_empty & need) {
+                    retry = true;  // someone nearer has not published yet
+                } else {
+                    part += ((int)lane <= p) ? (sv[j] & kStatusMask) : 0ull;
+                    if (p < 64) done = true;
+                }
+            }
+        }
+        if (retry) { __builtin_amdgcn_s_sleep(1); continue; }  // keep what is already summed? no: re-read all
+        excl += wave_reduce_sum(part);
+        if (done) break;
+        b -= (int64_t)kLookWin * kWave;
     }
     if (lane == 0 && t != 0)
         __hip_atomic_store(&status[t], kStatusPrefix | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return excl;
 }
 
+// One merge tile: rows [ra, ra+nr) whose partial products are staging[s, s+n).
+struct TileDesc {
+    uint64_t s;
+    uint32_t ra, nr, n, pad;
+};
+template <int CAP>
+__global__ void tile_desc_kernel(const uint32_t *tile_rows, uint32_t ntiles, uint64_t r_end, const uint64_t *row_off,
+                                 uint64_t base, TileDesc *desc) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    const uint64_t ra = tile_rows[t], rb = (t + 1 < ntiles) ? (uint64_t)tile_rows[t + 1] : r_end;
+    TileDesc d;
+    d.s = row_off[ra] - base;
+    d.ra = (uint32_t)ra;
+    d.nr = (uint32_t)(rb - ra);
+    d.n = (uint32_t)min(row_off[rb] - base - d.s, (uint64_t)CAP + 1);  // CAP+1 = "a single long row"
+    d.pad = 0;
+    desc[t] = d;
+}
+
 // ABL: ablation switches for tools/bench_merge.hip only (1 = no sort, 2 = no look-back, 4 = no ticket);
 // the library always instantiates ABL = 0.
+//
+// Persistent workgroups: each takes tiles from the ticket counter until none are left.  The ticket and
+// the descriptor of the NEXT tile are fetched by thread 0 while the current tile is being merged, and a
+// tile's row offsets and partial products are requested together, so one tile costs one exposed HBM
+// round trip instead of a chain of five.
 template <class T, int NT, int ABL = 0>
-__global__ __launch_bounds__(NT) void merge_tiles_kernel(
-    const uint32_t *__restrict__ tile_rows, uint32_t ntiles, uint64_t r_end,
+__global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two workgroups per CU
+    const TileDesc *__restrict__ desc, uint32_t ntiles, uint64_t r_end,
     const uint64_t *__restrict__ row_off, uint64_t base, int colbits, const uint32_t *__restrict__ pcol,
     const T *__restrict__ pval, const uint32_t *__restrict__ heavy_nnz, uint64_t *tile_status,
     uint32_t *ticket, const uint64_t *__restrict__ out_base_p, int64_t *__restrict__ c_rowptr,
     uint32_t *__restrict__ c_col, T *__restrict__ c_val, uint64_t *__restrict__ out_end_p) {
     __shared__ MergeSmem<T, NT> sm;
+    __shared__ TileDesc s_dnext;
+    __shared__ uint32_t s_tnext;
     constexpr int kTileCap = TileCap<T>::value;
     constexpr int NW = NT / kWave;
+    constexpr int LPT = (kTileCap + NT - 1) / NT;
+    constexpr int ITERS = (kTileCap / NW + kWave - 1) / kWave;  // wave iterations per sort pass
+    constexpr int IPT = LPT;
+    static_assert(NT >= kDigits, "one thread per digit in the scan step");
+    static_assert(kTileMaxRows + 1 <= NT, "row offsets are fetched one per thread");
     const unsigned tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
-    if (tid == 0) sm.tile = (ABL & 4) ? blockIdx.x : atomicAdd(ticket, 1u);
-    __syncthreads();
-    const uint32_t t = sm.tile;
-    if (t >= ntiles) return;
-    const uint64_t out_base = *out_base_p;
-    const uint64_t ra = tile_rows[t];
-    const uint64_t rb = (t + 1 < ntiles) ? (uint64_t)tile_rows[t + 1] : r_end;
-    const uint32_t nr = (uint32_t)(rb - ra);
-    const uint64_t s = row_off[ra] - base;
-    const uint32_t n = (uint32_t)min(row_off[rb] - base - s, (uint64_t)kTileCap + 1);
-    if (n > (uint32_t)kTileCap) {
-        // a single long row, already reduced in place by the global-sort path: only take part in the
-        // offset chain; heavy_copy_kernel moves its entries once c_rowptr is known
-        if (w == 0) {
-            const uint64_t total = heavy_nnz[ra];
-            const uint64_t excl = lookback_prefix(tile_status, t, total);
-            if (lane == 0) {
-                c_rowptr[ra] = (int64_t)(out_base + excl);
-                if (t + 1 == ntiles) { c_rowptr[r_end] = (int64_t)(out_base + excl + total); *out_end_p = out_base + excl + total; }
-            }
-        }
-        return;
+    if (tid == 0) {
+        const uint32_t t0 = (ABL & 4) ? blockIdx.x : atomicAdd(ticket, 1u);
+        s_tnext = t0;
+        if (t0 < ntiles) s_dnext = desc[t0];
     }
-    for (uint32_t r = tid; r <= nr; r += NT) sm.rowo[r] = (uint32_t)(row_off[ra + r] - base - s);
     __syncthreads();
-    // stage: key = (local row << colbits) | col, payload = staging position.  All global loads of a
-    // thread are issued before the first LDS write so that a wave keeps ~5 KB of HBM reads in flight.
-    {
-        constexpr int LPT = (kTileCap + NT - 1) / NT;
-        uint32_t lc[LPT];
-        T lv[LPT];
+    const uint64_t out_base = *out_base_p;
+    const uint32_t colmask = colbits < 32 ? ((1u << colbits) - 1u) : 0xffffffffu;
+    // the first tile's data is requested here; inside the loop the NEXT tile's data is requested while the
+    // current tile's output is being written
+    uint32_t t = s_tnext;
+    TileDesc d = s_dnext;
+    uint64_t ro = 0;
+    uint32_t lc[LPT];
+    T lv[LPT];
+    auto request = [&](const TileDesc &dd, bool ok) {
+        const bool fetch = ok && dd.n <= (uint32_t)kTileCap;
+        ro = 0;
+        if (fetch && tid <= dd.nr) ro = row_off[dd.ra + tid];
 #pragma unroll
         for (int q = 0; q < LPT; q++) {
             const uint32_t i = tid + q * NT;
             lc[q] = 0; lv[q] = 0;
-            if (i < n) { lc[q] = pcol[s + i]; lv[q] = pval[s + i]; }
+            if (fetch && i < dd.n) { lc[q] = pcol[dd.s + i]; lv[q] = pval[dd.s + i]; }
         }
+    };
+    request(d, t < ntiles);
+    __syncthreads();  // everybody holds t / d before the slots are refilled
+    while (t < ntiles) {
+        const uint64_t ra = d.ra, s = d.s;
+        const uint32_t nr = d.nr, n = d.n;
+        const bool long_row = n > (uint32_t)kTileCap;
+        // The next tile's ticket is taken only AFTER this tile's look-back has returned: a workgroup that
+        // is still waiting for its predecessors must not sit on a ticket, or every later tile queues up
+        // behind it (measured: 4x slower merge with an early ticket).
+        uint32_t tn_reg = ntiles;
+        if (long_row) {
+            // a single long row, already reduced by the split / global-sort path: it only takes part in the
+            // offset chain; heavy_copy_kernel moves its entries once c_rowptr is known
+            if (w == 0) {
+                const uint64_t total = heavy_nnz[ra];
+                const uint64_t excl = (ABL & 2) ? (uint64_t)t * kTileCap : lookback_prefix(tile_status, t, total);
+                if (lane == 0) {
+                    tn_reg = (ABL & 4) ? t + gridDim.x : atomicAdd(ticket, 1u);
+                    c_rowptr[ra] = (int64_t)(out_base + excl);
+                    if (t + 1 == ntiles) { c_rowptr[r_end] = (int64_t)(out_base + excl + total); *out_end_p = out_base + excl + total; }
+                    s_tnext = tn_reg;
+                    if (tn_reg < ntiles) s_dnext = desc[tn_reg];
+                }
+            }
+            __syncthreads();
+            t = s_tnext;
+            d = s_dnext;
+            request(d, t < ntiles);
+            __syncthreads();
+            continue;
+        }
+        if (tid <= nr) sm.rowo[tid] = (uint32_t)(ro - base - s);
+        __syncthreads();
+        // stage: key = (local row << colbits) | col, payload = staging position
 #pragma unroll
         for (int q = 0; q < LPT; q++) {
             const uint32_t i = tid + q * NT;
             if (i < n) {
                 uint32_t lo = 0, hi = nr;  // last r with rowo[r] <= i
-                while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (sm.rowo[mid] <= i) lo = mid; else hi = mid; }
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sm.rowo[mid] <= i) lo = mid; else hi = mid; }
                 sm.key[0][i] = (colbits < 32 ? (lo << colbits) : 0u) | lc[q];
                 sm.pos[0][i] = (uint16_t)i;
                 sm.val[i] = lv[q];
             }
         }
-    }
-    int rowbits = 0;
-    while ((1u << rowbits) < nr) rowbits++;
-    const int nbits = (n && !(ABL & 1)) ? colbits + rowbits : 0;
-    // each wave ranks a contiguous span, so earlier waves = earlier positions (stable)
-    constexpr int ITERS = (kTileCap / NW + kWave - 1) / kWave;  // wave iterations per pass
-    static_assert(NT >= kDigits, "one thread per digit in the scan step");
-    const uint32_t per = (n + NW - 1) / NW;
-    const uint32_t wbeg = min(w * per, n), wend = min(wbeg + per, n);
-    int cur = 0;
-    __syncthreads();
-    const int npass = (nbits + kDigitBits - 1) / kDigitBits;
-    const int pbits = npass ? (nbits + npass - 1) / npass : 0;  // balanced digit width (<= kDigitBits)
-    const uint32_t dmask = (1u << pbits) - 1u;
-    for (int pass = 0, shift = 0; pass < npass; pass++, shift += pbits) {
-        for (int d = lane; d < kDigits; d += kWave) sm.cnt[w][d] = 0;
-        // (a) rank inside the wave's span; keys and ranks stay in registers for (c)
-        uint32_t kreg[ITERS], rreg[ITERS];
-#pragma unroll
-        for (int it = 0; it < ITERS; it++) {
-            const uint32_t i = wbeg + it * kWave + lane;
-            const bool valid = i < wend;
-            kreg[it] = valid ? sm.key[cur][i] : 0u;
-            const unsigned d = (kreg[it] >> shift) & dmask;
-            unsigned rk, cntd;
-            wave_match_digit(d, valid, rk, cntd);
-            if (valid) {
-                const uint32_t c = sm.cnt[w][d];
-                rreg[it] = c + rk;
-                if (rk == 0) sm.cnt[w][d] = (uint16_t)(c + cntd);
-            }
-        }
+        int rowbits = 0;
+        while ((1u << rowbits) < nr) rowbits++;
+        const int nbits = (n && !(ABL & 1)) ? colbits + rowbits : 0;
+        // each wave ranks a contiguous span, so earlier waves = earlier positions (stable)
+        const uint32_t per = (n + NW - 1) / NW;
+        const uint32_t wbeg = min(w * per, n), wend = min(wbeg + per, n);
+        int cur = 0;
         __syncthreads();
-        // (b) exclusive scan over (digit major, wave minor); thread d owns digit d
-        {
-            uint32_t c[NW], ssum = 0;
-            if (tid < kDigits) {
+        const int npass = (nbits + kDigitBits - 1) / kDigitBits;
+        const int pbits = npass ? (nbits + npass - 1) / npass : 0;  // balanced digit width (<= kDigitBits)
+        const uint32_t dmask = (1u << pbits) - 1u;
+        for (int pass = 0, shift = 0; pass < npass; pass++, shift += pbits) {
+            for (int dd = lane; dd < kDigits; dd += kWave) sm.cnt[w][dd] = 0;
+            // (a) rank inside the wave's span; keys and ranks stay in registers for (c)
+            uint32_t kreg[ITERS], rreg[ITERS];
 #pragma unroll
-                for (int ww = 0; ww < NW; ww++) { c[ww] = sm.cnt[ww][tid]; ssum += c[ww]; }
+            for (int it = 0; it < ITERS; it++) {
+                const uint32_t i = wbeg + it * kWave + lane;
+                const bool valid = i < wend;
+                kreg[it] = valid ? sm.key[cur][i] : 0u;
+                const unsigned dg = (kreg[it] >> shift) & dmask;
+                unsigned rk, cntd;
+                wave_match_digit(dg, valid, rk, cntd);
+                rreg[it] = 0;
+                if (valid) {
+                    const uint32_t c = sm.cnt[w][dg];
+                    rreg[it] = c + rk;
+                    if (rk == 0) sm.cnt[w][dg] = (uint16_t)(c + cntd);
+                }
             }
-            uint32_t total;
-            uint32_t ex = block_excl_scan<uint32_t, NT>(ssum, sm.scratch, &total);
-            if (tid < kDigits) {
+            __syncthreads();
+            // (b) exclusive scan over (digit major, wave minor); thread dg owns digit dg
+            {
+                uint32_t c[NW], ssum = 0;
+                if (tid < kDigits) {
 #pragma unroll
-                for (int ww = 0; ww < NW; ww++) { sm.cnt[ww][tid] = (uint16_t)ex; ex += c[ww]; }
+                    for (int ww = 0; ww < NW; ww++) { c[ww] = sm.cnt[ww][tid]; ssum += c[ww]; }
+                }
+                uint32_t total;
+                uint32_t ex = block_excl_scan<uint32_t, NT>(ssum, sm.scratch, &total);
+                if (tid < kDigits) {
+#pragma unroll
+                    for (int ww = 0; ww < NW; ww++) { sm.cnt[ww][tid] = (uint16_t)ex; ex += c[ww]; }
+                }
+            }
+            __syncthreads();
+            // (c) scatter
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) {
+                const uint32_t i = wbeg + it * kWave + lane;
+                if (i < wend) {
+                    const uint32_t k = kreg[it];
+                    const uint32_t dst = (uint32_t)sm.cnt[w][(k >> shift) & dmask] + rreg[it];
+                    sm.key[cur ^ 1][dst] = k;
+                    sm.pos[cur ^ 1][dst] = sm.pos[cur][i];
+                }
+            }
+            cur ^= 1;
+            __syncthreads();
+        }
+        // head flags + exclusive scan (blocked: thread owns IPT consecutive sorted entries)
+        const uint32_t ib = tid * IPT;
+        uint32_t heads = 0, hmask = 0;
+#pragma unroll
+        for (int q = 0; q < IPT; q++) {
+            const uint32_t i = ib + q;
+            if (i < n) {
+                const bool h = (i == 0) || (sm.key[cur][i] != sm.key[cur][i - 1]);
+                hmask |= (h ? 1u : 0u) << q;
+                heads += h;
             }
         }
+        uint32_t total;
+        uint32_t ex = block_excl_scan<uint32_t, NT>(heads, sm.scratch, &total);
+        // the tile's unique count is known: wave 0 runs the look-back and then requests the next ticket;
+        // the ticket's round trip overlaps the run sums below
+        if (w == 0) {
+            const uint64_t excl = (ABL & 2) ? (uint64_t)t * kTileCap : lookback_prefix(tile_status, t, total);
+            if (lane == 0) {
+                sm.excl = excl;
+                tn_reg = (ABL & 4) ? t + gridDim.x : atomicAdd(ticket, 1u);
+            }
+        }
+        uint32_t oslot[IPT];
+#pragma unroll
+        for (int q = 0; q < IPT; q++) {
+            const uint32_t i = ib + q;
+            oslot[q] = ex;
+            if (i < n) {
+                sm.rank[i] = (uint16_t)ex;  // output slot of the run that starts at/behind i
+                ex += (hmask >> q) & 1u;
+            }
+        }
+        if (tid == 0) sm.rank[n] = (uint16_t)total;
+        // each head sums its run in staging order (= ascending k)
+        T acc[IPT];
+        uint32_t ocol[IPT];
+#pragma unroll
+        for (int q = 0; q < IPT; q++) {
+            const uint32_t i = ib + q;
+            acc[q] = 0; ocol[q] = 0;
+            if (i < n && ((hmask >> q) & 1u)) {
+                const uint32_t k = sm.key[cur][i];
+                T a = sm.val[sm.pos[cur][i]];
+                for (uint32_t u = i + 1; u < n && sm.key[cur][u] == k; u++) a += sm.val[sm.pos[cur][u]];
+                acc[q] = a;
+                ocol[q] = k & colmask;
+            }
+        }
+        if (tid == 0) s_tnext = tn_reg;
+        __syncthreads();  // all gathers from val[] / key[cur] done; sm.excl and s_tnext are published
+        // compact into LDS (val[] and the idle key buffer), then stream out with consecutive lanes on
+        // consecutive addresses
+#pragma unroll
+        for (int q = 0; q < IPT; q++) {
+            const uint32_t i = ib + q;
+            if (i < n && ((hmask >> q) & 1u)) { sm.key[cur ^ 1][oslot[q]] = ocol[q]; sm.val[oslot[q]] = acc[q]; }
+        }
+        if (tid == 0 && tn_reg < ntiles) s_dnext = desc[tn_reg];
         __syncthreads();
-        // (c) scatter
-#pragma unroll
-        for (int it = 0; it < ITERS; it++) {
-            const uint32_t i = wbeg + it * kWave + lane;
-            if (i < wend) {
-                const uint32_t k = kreg[it];
-                const uint32_t dst = (uint32_t)sm.cnt[w][(k >> shift) & dmask] + rreg[it];
-                sm.key[cur ^ 1][dst] = k;
-                sm.pos[cur ^ 1][dst] = sm.pos[cur][i];
-            }
-        }
-        cur ^= 1;
-        __syncthreads();
+        const uint32_t tn = s_tnext;
+        const TileDesc dn = s_dnext;
+        // the next tile's HBM reads go out ahead of this tile's writes
+        request(dn, tn < ntiles);
+        const uint64_t obase = out_base + sm.excl;
+        for (uint32_t o = tid; o < total; o += NT) { c_col[obase + o] = sm.key[cur ^ 1][o]; c_val[obase + o] = sm.val[o]; }
+        // rows keep their index span through the sort (row is the major key)
+        if (tid < nr) c_rowptr[ra + tid] = (int64_t)(obase + sm.rank[sm.rowo[tid]]);
+        if (t + 1 == ntiles && tid == 0) { c_rowptr[r_end] = (int64_t)(obase + total); *out_end_p = obase + total; }
+        t = tn;
+        d = dn;
+        __syncthreads();  // LDS is reused by the next tile
     }
-    // head flags + exclusive scan (blocked: thread owns IPT consecutive sorted entries)
-    constexpr int IPT = (kTileCap + NT - 1) / NT;
-    const uint32_t ib = tid * IPT;
-    uint32_t heads = 0, hmask = 0;
-#pragma unroll
-    for (int q = 0; q < IPT; q++) {
-        const uint32_t i = ib + q;
-        if (i < n) {
-            const bool h = (i == 0) || (sm.key[cur][i] != sm.key[cur][i - 1]);
-            hmask |= (h ? 1u : 0u) << q;
-            heads += h;
-        }
-    }
-    uint32_t total;
-    uint32_t ex = block_excl_scan<uint32_t, NT>(heads, sm.scratch, &total);
-    // the tile's unique count is known: start the look-back now, it overlaps the run sums below
-    if (w == 0) {
-        const uint64_t excl = (ABL & 2) ? (uint64_t)t * kTileCap : lookback_prefix(tile_status, t, total);
-        if (lane == 0) sm.excl = excl;
-    }
-    uint32_t oslot[IPT];
-#pragma unroll
-    for (int q = 0; q < IPT; q++) {
-        const uint32_t i = ib + q;
-        oslot[q] = ex;
-        if (i < n) {
-            sm.rank[i] = (uint16_t)ex;  // output slot of the run that starts at/behind i
-            ex += (hmask >> q) & 1u;
-        }
-    }
-    if (tid == 0) sm.rank[n] = (uint16_t)total;
-    // each head sums its run in staging order (= ascending k)
-    const uint32_t colmask = colbits < 32 ? ((1u << colbits) - 1u) : 0xffffffffu;
-    T acc[IPT];
-    uint32_t ocol[IPT];
-#pragma unroll
-    for (int q = 0; q < IPT; q++) {
-        const uint32_t i = ib + q;
-        acc[q] = 0; ocol[q] = 0;
-        if (i < n && ((hmask >> q) & 1u)) {
-            const uint32_t k = sm.key[cur][i];
-            T a = sm.val[sm.pos[cur][i]];
-            for (uint32_t u = i + 1; u < n && sm.key[cur][u] == k; u++) a += sm.val[sm.pos[cur][u]];
-            acc[q] = a;
-            ocol[q] = k & colmask;
-        }
-    }
-    __syncthreads();  // all gathers from val[] / key[cur] done; look-back result published in sm.excl
-    // compact into LDS (val[] and the idle key buffer), then stream out with consecutive lanes on
-    // consecutive addresses
-#pragma unroll
-    for (int q = 0; q < IPT; q++) {
-        const uint32_t i = ib + q;
-        if (i < n && ((hmask >> q) & 1u)) { sm.key[cur ^ 1][oslot[q]] = ocol[q]; sm.val[oslot[q]] = acc[q]; }
-    }
-    __syncthreads();
-    const uint64_t obase = out_base + sm.excl;
-    for (uint32_t o = tid; o < total; o += NT) { c_col[obase + o] = sm.key[cur ^ 1][o]; c_val[obase + o] = sm.val[o]; }
-    // rows keep their index span through the sort (row is the major key)
-    for (uint32_t r = tid; r < nr; r += NT) c_rowptr[ra + r] = (int64_t)(obase + sm.rank[sm.rowo[r]]);
-    if (t + 1 == ntiles && tid == 0) { c_rowptr[r_end] = (int64_t)(obase + total); *out_end_p = obase + total; }
 }
 
 // ---- merge: global-sort path for rows longer than kTileCap ---------------------------------------

@@ -63,6 +63,7 @@ __global__ void tiles_kernel(uint32_t *tile_rows, uint32_t ntiles, uint32_t rpt)
     if (i < ntiles) tile_rows[i] = i * rpt;
 }
 
+TileDesc *g_desc; uint32_t g_grid = 512;
 template <int NT, int ABL>
 float run(uint32_t *tile_rows, uint32_t ntiles, uint64_t M, uint64_t *row_off, uint32_t *pcol, double *pval,
           uint32_t *heavy, uint64_t *status, uint32_t *ticket, uint64_t *outn, int64_t *rowptr, uint32_t *ccol, double *cval) {
@@ -72,7 +73,7 @@ float run(uint32_t *tile_rows, uint32_t ntiles, uint64_t M, uint64_t *row_off, u
     CK(hipMemsetAsync(ticket, 0, 4, 0));
     CK(hipMemsetAsync(outn, 0, 16, 0));
     CK(hipEventRecord(a, 0));
-    merge_tiles_kernel<double, NT, ABL><<<ntiles, NT, 0, 0>>>(tile_rows, ntiles, M, row_off, 0, 22, pcol, pval, heavy, status,
+    merge_tiles_kernel<double, NT, ABL><<<ntiles < g_grid ? ntiles : g_grid, NT, 0, 0>>>(g_desc, ntiles, M, row_off, 0, 22, pcol, pval, heavy, status,
                                                               ticket, outn, rowptr, ccol, cval, outn + 1);
     CK(hipEventRecord(b, 0));
     CK(hipEventSynchronize(b));
@@ -101,15 +102,17 @@ int main(int argc, char **argv) {
     arow_kernel<<<(unsigned)((M + 256) / 256), 256>>>(g_arow, M, rowlen / clen);
     rows_kernel<<<(unsigned)((M + 256) / 256), 256>>>(row_off, M, rowlen);
     tiles_kernel<<<(ntiles + 255) / 256, 256>>>(tile_rows, ntiles, rpt);
+    CK(hipMalloc(&g_desc, (uint64_t)ntiles * sizeof(TileDesc)));
+    tile_desc_kernel<3072><<<(ntiles + 255) / 256, 256>>>(tile_rows, ntiles, M, row_off, 0, g_desc);
+    if (getenv("GRID")) g_grid = atoi(getenv("GRID"));
     CK(hipDeviceSynchronize());
     printf("P=%llu partials, %u tiles of %u rows x %u (%u per tile), algorithmic bytes %.2f GB\n", (unsigned long long)P, ntiles, rpt,
            rowlen, rpt * rowlen, (12.0 * P * 2) / 1e9);
 #define ARGS tile_rows, ntiles, M, row_off, pcol, pval, heavy, status, ticket, outn, rowptr, ccol, cval
     struct V { const char *name; float (*fn)(uint32_t *, uint32_t, uint64_t, uint64_t *, uint32_t *, double *, uint32_t *, uint64_t *, uint32_t *, uint64_t *, int64_t *, uint32_t *, double *); };
     std::vector<V> vs = {
-        {"radix NT512 full", run<512, 0>}, {"radix NT1024 full", run<1024, 0>}, {"radix NT512 nosort", run<512, 1>},
-        {"runs NT512 full", run_runs<512, 0>}, {"runs NT256 full", run_runs<256, 0>}, {"runs NT1024 full", run_runs<1024, 0>},
-        {"runs NT512 nomerge", run_runs<512, 1>}, {"runs NT512 nolb+notick", run_runs<512, 6>},
+        {"radix NT512 full", run<512, 0>}, {"radix NT512 nosort", run<512, 1>}, {"radix NT512 nolb", run<512, 2>},
+        {"radix NT512 nosort+nolb", run<512, 3>}, {"runs NT1024 full", run_runs<1024, 0>},
     };
     std::vector<std::vector<float>> t(vs.size());
     for (int round = 0; round < 5; round++)
