@@ -44,8 +44,22 @@ def rmat_device(scale, ef, abcd, seed, device, dtype):
     """R-MAT on the GPU (same recipe as outerspace_amd.generators.rmat_coo), duplicates removed.
     Returns CSR and CSC arrays of the same matrix as torch tensors (int64 ptr, int32 idx)."""
     import torch
-    a, b, c, _ = abcd
     n, m = 1 << scale, ef << scale
+    if abcd == "regular":  # experiment only: every row has exactly `ef` non-zeros (all chunks equally long)
+        g = torch.Generator(device=device); g.manual_seed(seed)
+        i = torch.arange(n, device=device, dtype=torch.int64).repeat_interleave(ef)
+        j = torch.arange(ef, device=device, dtype=torch.int64).repeat(n)
+        shift = torch.randint(0, n // ef, (ef,), generator=g, device=device, dtype=torch.int64)
+        mix = (i * 2654435761) % (n // ef)
+        rows, cols = i, (j * (n // ef) + (mix + shift[j]) % (n // ef)) % n
+        key = torch.unique(rows * n + cols)
+        rows, cols = key // n, key % n
+        vals = torch.rand(rows.numel(), generator=g, device=device, dtype=dtype) + 0.5
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device); rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+        colptr = torch.zeros(n + 1, dtype=torch.int64, device=device); colptr[1:] = torch.cumsum(torch.bincount(cols, minlength=n), 0)
+        perm = torch.argsort(cols * n + rows)
+        return n, (rowptr, cols.to(torch.int32).contiguous(), vals), (colptr, rows[perm].to(torch.int32).contiguous(), vals[perm].contiguous())
+    a, b, c, _ = abcd
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     rows = torch.zeros(m, dtype=torch.int64, device=device)
@@ -129,7 +143,8 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    abcd = gen.RMAT_PRESETS[args.rmat] if args.rmat in gen.RMAT_PRESETS else tuple(float(x) for x in args.rmat.split(","))
+    abcd = "regular" if args.rmat == "regular" else (
+        gen.RMAT_PRESETS[args.rmat] if args.rmat in gen.RMAT_PRESETS else tuple(float(x) for x in args.rmat.split(",")))
     tdtype = torch.float64 if args.dtype == "f64" else torch.float32
     np_dtype = np.float64 if args.dtype == "f64" else np.float32
     E = 4 + np.dtype(np_dtype).itemsize

@@ -19,6 +19,7 @@
 #include "osp_kernels.h"
 #include "osp_merge_runs.h"
 #include "osp_split.h"
+#include "osp_sort.h"
 
 namespace osp {
 
@@ -533,26 +534,27 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         OSP_HIP(hipMemsetAsync(chunk_start, 0, sizeof(uint64_t), s));
     } else {
         Scratch ss(ctx);
-        uint32_t *keys[2] = {ss.get<uint32_t>(nnz), ss.get<uint32_t>(nnz)};
-        uint32_t *perm[2] = {ss.get<uint32_t>(nnz), ss.get<uint32_t>(nnz)};
-        uint32_t *w = ss.get<uint32_t>(nnz);
-        uint32_t *hist = ss.get<uint32_t>(sort_hist_entries(nnz));
-        uint32_t *hist_tmp = ss.get<uint32_t>(scan_scratch_entries(sort_hist_entries(nnz)));
+        uint32_t *ka = ss.get<uint32_t>(nnz), *pa = ss.get<uint32_t>(nnz), *kb = ss.get<uint32_t>(nnz), *pb = ss.get<uint32_t>(nnz);
+        uint32_t *rows_sorted = ss.get<uint32_t>(nnz), *perm = ss.get<uint32_t>(nnz), *w_sorted = ss.get<uint32_t>(nnz);
+        uint32_t *hist = ss.get<uint32_t>(rs_hist_entries(nnz));
+        uint32_t *hist_tmp = ss.get<uint32_t>(scan_scratch_entries(rs_hist_entries(nnz)));
         uint64_t *offs_sorted = ss.get<uint64_t>(nnz + 1);
         uint32_t *ne_scan = ss.get<uint32_t>(nnz + 1);
         uint64_t *scan_tmp = ss.get<uint64_t>(scan_scratch_entries(nnz));
-        sym_expand_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(a_colptr, a_rowidx, b_rowptr, k0, k1, e0, nnz, keys[0],
-                                                             perm[0], w);
-        const int cur = device_radix_sort_pairs<uint32_t>(keys, perm, nnz, std::max(1, bits_for(M)), hist, hist_tmp, s);
-        device_exclusive_scan<LoadGatherW, uint64_t>(LoadGatherW{w, perm[cur]}, nnz, offs_sorted, scan_tmp, s);
+        // (row, k) order of A's non-zeros; the last sort pass also looks up each chunk's length
+        uint32_t *w = ss.get<uint32_t>(nnz);
+        sym_chunk_len_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(a_colptr, b_rowptr, k0, k1, e0, nnz, w);
+        device_sort_rows<SymEpilogue>(a_rowidx + e0, nnz, std::max(1, bits_for(M)), ka, pa, kb, pb, hist, hist_tmp,
+                                      SymEpilogue{w, rows_sorted, perm, w_sorted}, s);
+        device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{w_sorted}, nnz, offs_sorted, scan_tmp, s);
         if (kMergeByRuns) {
-            const NonEmptyFlag<LenGatherW> nef{LenGatherW{w, perm[cur]}};
-            device_exclusive_scan<NonEmptyFlag<LenGatherW>, uint32_t>(nef, nnz, ne_scan, (uint32_t *)scan_tmp, s);
-            chunk_compact_kernel<LenGatherW><<<grid_for(nnz + 1, 256), 256, 0, s>>>(LenGatherW{w, perm[cur]}, offs_sorted,
-                                                                                    ne_scan, nnz, chunk_start);
+            const NonEmptyFlag<LoadU32> nef{LoadU32{w_sorted}};
+            device_exclusive_scan<NonEmptyFlag<LoadU32>, uint32_t>(nef, nnz, ne_scan, (uint32_t *)scan_tmp, s);
+            chunk_compact_kernel<LoadU32><<<grid_for(nnz + 1, 256), 256, 0, s>>>(LoadU32{w_sorted}, offs_sorted, ne_scan, nnz,
+                                                                                chunk_start);
         }
-        sym_scatter_offsets_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(perm[cur], offs_sorted, nnz, chunk_off);
-        sym_row_offsets_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(keys[cur], offs_sorted, kMergeByRuns ? ne_scan : nullptr,
+        sym_scatter_offsets_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(perm, offs_sorted, nnz, chunk_off);
+        sym_row_offsets_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(rows_sorted, offs_sorted, kMergeByRuns ? ne_scan : nullptr,
                                                                     nnz, M, row_off, arow);
         P = d2h(offs_sorted + nnz, s);
     }

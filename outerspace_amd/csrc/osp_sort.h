@@ -1,0 +1,184 @@
+// osp_sort.h -- the symbolic phase's sort: stable LSD radix sort of (row, A-entry) pairs, 8-bit
+// digits, written for gfx950 (wave64, 160 KiB LDS).
+//
+// Why it exists: the staging layout needs the non-zeros of A (given in CSC order) in (row, k) order.
+// The reference gets its orderings from std::sort on the host (coo2csr, SimSpGEMM.cpp:111-121).
+//
+// Per pass: one histogram launch (per-workgroup digit counts, digit-major), one device scan, one
+// scatter launch.  A workgroup owns 8192 consecutive elements; ranking is per-wave match (8 ballots)
+// with wave-private LDS counters; the elements are first reordered inside LDS so that every digit's
+// run leaves the workgroup as one contiguous, coalesced store.
+//   * the FIRST pass reads its keys straight from A's row indices (payload = position, implicit),
+//   * the LAST pass hands every sorted element to an epilogue functor (here: chunk length lookup),
+// so no (key, payload) arrays are materialised before the first or after the last pass.
+#pragma once
+#include "osp_kernels.h"
+
+namespace osp {
+
+constexpr int kRsThreads = 512;
+constexpr int kRsItems = 16;
+constexpr int kRsTile = kRsThreads * kRsItems;  // 8192 elements per workgroup
+
+inline uint32_t rs_blocks(uint64_t n) { return (uint32_t)((n + kRsTile - 1) / kRsTile); }
+inline uint64_t rs_hist_entries(uint64_t n) { return (uint64_t)rs_blocks(n) * kRadix + 1; }
+
+// FIRST: keys_in is the raw key array and the payload is the element index
+template <bool FIRST>
+__global__ __launch_bounds__(kRsThreads) void rs_hist_kernel(const uint32_t *__restrict__ keys_in, uint64_t n, int shift,
+                                                             uint32_t *__restrict__ hist, uint32_t nblocks) {
+    __shared__ uint32_t h[kRadix];
+    if (threadIdx.x < kRadix) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * kRsTile;
+#pragma unroll
+    for (int q = 0; q < kRsItems; q++) {
+        const uint64_t i = base + (uint64_t)q * kRsThreads + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys_in[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kRadix) hist[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+struct RsNoEpilogue {
+    __device__ void operator()(uint64_t, uint32_t, uint32_t) const {}
+};
+
+template <bool FIRST, bool LAST, class Epi>
+__global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, uint64_t n, int shift, const uint32_t *__restrict__ hist_scan, uint32_t nblocks,
+    Epi epi) {
+    constexpr int NW = kRsThreads / kWave;
+    constexpr int SPAN = kRsTile / NW;      // contiguous elements per wave
+    constexpr int ITERS = SPAN / kWave;     // 16
+    __shared__ uint32_t skey[kRsTile];
+    __shared__ uint32_t sval[kRsTile];
+    __shared__ uint16_t cnt[NW][kRadix];
+    __shared__ uint32_t lstart[kRadix];     // first LDS slot of each digit
+    __shared__ uint32_t gbase[kRadix];      // first global slot of each digit for this workgroup
+    __shared__ uint32_t scratch[NW + 1];
+    const unsigned tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const uint64_t tile = (uint64_t)blockIdx.x * kRsTile;
+    for (int d = lane; d < kRadix; d += kWave) cnt[w][d] = 0;
+    if (tid < kRadix) gbase[tid] = hist_scan[(uint64_t)tid * nblocks + blockIdx.x];
+    // wave w owns elements [tile + w*SPAN, +SPAN): earlier waves = earlier elements (stable)
+    uint32_t kreg[ITERS], vreg[ITERS], rreg[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const uint64_t i = tile + (uint64_t)w * SPAN + (uint64_t)it * kWave + lane;
+        kreg[it] = 0; vreg[it] = 0;
+        if (i < n) {
+            kreg[it] = keys_in[i];
+            vreg[it] = FIRST ? (uint32_t)i : vals_in[i];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const uint64_t i = tile + (uint64_t)w * SPAN + (uint64_t)it * kWave + lane;
+        const bool valid = i < n;
+        const unsigned d = (kreg[it] >> shift) & 255u;
+        const uint64_t peers = wave_match8(d, valid);
+        const unsigned rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        rreg[it] = 0;
+        if (valid) {
+            const uint32_t c = cnt[w][d];
+            rreg[it] = c + rk;
+            if (rk == 0) cnt[w][d] = (uint16_t)(c + (uint32_t)__popcll(peers));
+        }
+    }
+    __syncthreads();
+    {   // digit totals -> LDS start of every digit, and per-wave offsets inside the digit
+        uint32_t c[NW], ssum = 0;
+        if (tid < kRadix) {
+#pragma unroll
+            for (int ww = 0; ww < NW; ww++) { c[ww] = cnt[ww][tid]; ssum += c[ww]; }
+        }
+        uint32_t total;
+        uint32_t ex = block_excl_scan<uint32_t, kRsThreads>(ssum, scratch, &total);
+        if (tid < kRadix) {
+            lstart[tid] = ex;
+#pragma unroll
+            for (int ww = 0; ww < NW; ww++) { cnt[ww][tid] = (uint16_t)ex; ex += c[ww]; }
+        }
+    }
+    __syncthreads();
+    // reorder inside LDS
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const uint64_t i = tile + (uint64_t)w * SPAN + (uint64_t)it * kWave + lane;
+        if (i < n) {
+            const uint32_t lp = (uint32_t)cnt[w][(kreg[it] >> shift) & 255u] + rreg[it];
+            skey[lp] = kreg[it];
+            sval[lp] = vreg[it];
+        }
+    }
+    __syncthreads();
+    // stream out: consecutive threads -> consecutive LDS slots -> consecutive global slots per digit
+    const uint32_t cnt_here = (uint32_t)min((uint64_t)kRsTile, n - tile);
+#pragma unroll
+    for (int q = 0; q < kRsItems; q++) {
+        const uint32_t j = tid + q * kRsThreads;
+        if (j < cnt_here) {
+            const uint32_t k = skey[j], v = sval[j];
+            const unsigned d = (k >> shift) & 255u;
+            const uint64_t g = (uint64_t)gbase[d] + (j - lstart[d]);
+            if (LAST) {
+                epi(g, k, v);
+            } else {
+                keys_out[g] = k;
+                vals_out[g] = v;
+            }
+        }
+    }
+}
+
+// Sort (keys_raw[i], i) by the low `nbits` bits of the key.  Buffers a and b are (key, payload) pairs
+// of n entries each; the last pass calls epi(sorted position, key, payload) instead of storing.
+// hist needs rs_hist_entries(n) u32, scan_scratch scan_scratch_entries(rs_hist_entries(n)).
+template <class Epi>
+inline void device_sort_rows(const uint32_t *keys_raw, uint64_t n, int nbits, uint32_t *ka, uint32_t *pa, uint32_t *kb,
+                             uint32_t *pb, uint32_t *hist, uint32_t *scan_scratch, Epi epi, hipStream_t stream) {
+    if (n == 0) return;
+    const uint32_t nb = rs_blocks(n);
+    const int npass = std::max(1, (nbits + 7) / 8);
+    const uint32_t *kin = keys_raw, *pin = nullptr;
+    uint32_t *kout = ka, *pout = pa;
+    for (int p = 0; p < npass; p++) {
+        const bool first = p == 0, last = p == npass - 1;
+        const int shift = 8 * p;
+        if (first) rs_hist_kernel<true><<<nb, kRsThreads, 0, stream>>>(kin, n, shift, hist, nb);
+        else rs_hist_kernel<false><<<nb, kRsThreads, 0, stream>>>(kin, n, shift, hist, nb);
+        device_exclusive_scan<LoadU32, uint32_t>(LoadU32{hist}, (uint64_t)nb * kRadix, hist, scan_scratch, stream);
+        if (first && last) rs_scatter_kernel<true, true, Epi><<<nb, kRsThreads, 0, stream>>>(kin, pin, kout, pout, n, shift, hist, nb, epi);
+        else if (first) rs_scatter_kernel<true, false, Epi><<<nb, kRsThreads, 0, stream>>>(kin, pin, kout, pout, n, shift, hist, nb, epi);
+        else if (last) rs_scatter_kernel<false, true, Epi><<<nb, kRsThreads, 0, stream>>>(kin, pin, kout, pout, n, shift, hist, nb, epi);
+        else rs_scatter_kernel<false, false, Epi><<<nb, kRsThreads, 0, stream>>>(kin, pin, kout, pout, n, shift, hist, nb, epi);
+        kin = kout; pin = pout;
+        if (kout == ka) { kout = kb; pout = pb; } else { kout = ka; pout = pa; }
+    }
+}
+
+// ---- symbolic epilogue: for the t-th A entry in (row, k) order ------------------------------------
+// rows_sorted[t] = its row, perm[t] = its CSC position (relative to e0), w_sorted[t] = its chunk length.
+// (The chunk lengths are looked up in CSC order beforehand -- sym_chunk_len_kernel -- where neighbouring
+// threads share a column; doing the column search here, in row order, cost 7.5 ms instead of 0.4.)
+struct SymEpilogue {
+    const uint32_t *w;  // chunk length per A entry, CSC order
+    uint32_t *rows_sorted, *perm, *w_sorted;
+    __device__ void operator()(uint64_t t, uint32_t row, uint32_t pos) const {
+        rows_sorted[t] = row;
+        perm[t] = pos;
+        w_sorted[t] = w[pos];
+    }
+};
+// w[t] = nnz(B[k,:]) for the t-th non-zero of A's shard (CSC order, column k)
+__global__ void sym_chunk_len_kernel(const int64_t *a_colptr, const int64_t *b_rowptr, uint64_t k0, uint64_t k1, int64_t e0,
+                                     uint64_t nnz, uint32_t *w) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nnz) return;
+    const uint64_t k = upper_bound_dev(a_colptr, k0, k1 + 1, e0 + (int64_t)t) - 1;
+    w[t] = (uint32_t)(b_rowptr[k + 1] - b_rowptr[k]);
+}
+
+}  // namespace osp
