@@ -163,15 +163,15 @@ template <class T> static T d2h(const T *dptr, hipStream_t s) {
 // Where the partial products of a panel come from.
 template <class T> struct Producer {
     virtual ~Producer() {}
-    // enqueue kernels that fill pcol/pval[0 .. row_off[r1]-row_off[r0]) for rows [r0,r1)
+    // enqueue kernels that fill stage[0 .. row_off[r1]-row_off[r0]) for rows [r0,r1)
     virtual void produce(uint64_t r0, uint64_t r1, bool whole, uint64_t base, uint64_t count,
-                         uint32_t *pcol, T *pval, PhaseTimer &tm) = 0;
+                         Part<T> *stage, PhaseTimer &tm) = 0;
 };
 
 // ---- rows of partial products -> merged rows -------------------------------------------------------
 // `rows` are real output rows (level 0) or the column-range segments of split long rows (level 1).
 template <class T> struct MergeIO {
-    uint32_t *pcol; T *pval;             // partial products of rows [r0,r1), addressed row_off[r] - base
+    Part<T> *stage;                      // partial products of rows [r0,r1), addressed row_off[r] - base
     const uint64_t *row_off; uint64_t r0, r1, base;
     int64_t *c_rowptr; uint32_t *c_col; T *c_val;  // output (c_rowptr indexed by absolute row id)
     const uint64_t *out_in; uint64_t *out_out;    // entries written before / after this call (device)
@@ -211,8 +211,9 @@ static void merge_rows(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO<
 
     Scratch hs(ctx);  // long-row buffers live until their entries have been copied into place
     uint64_t *heavy_src = nullptr;
-    const uint32_t *hcopy_col = io.pcol;
-    const T *hcopy_val = io.pval;
+    const Part<T> *hcopy_stage = io.stage;  // where the long rows' merged entries are copied from
+    const uint32_t *hcopy_col = nullptr;
+    const T *hcopy_val = nullptr;
     if (nheavy) {
         heavy_src = hs.get<uint64_t>(nheavy);
         uint64_t *hoff = hs.get<uint64_t>((uint64_t)nheavy + 1);
@@ -239,13 +240,13 @@ static void merge_rows(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO<
             uint32_t *ghist = hs.get<uint32_t>(ncell + 1);
             uint32_t *ghist_tmp = hs.get<uint32_t>(scan_scratch_entries(ncell + 1));
             split_count_kernel<<<(unsigned)nblocks, kSplitThreads, 0, s>>>(heavy_rows, nheavy, blkbase, hbase, hbits, nstretch,
-                                                                         io.row_off, base, colbits, io.pcol, ghist);
+                                                                         io.row_off, base, colbits, (const char *)io.stage,
+                                                                         (uint32_t)sizeof(Part<T>), ghist);
             device_exclusive_scan<LoadU32, uint32_t>(LoadU32{ghist}, ncell, ghist, ghist_tmp, s);
-            uint32_t *qcol = hs.get<uint32_t>(nh);
-            T *qval = hs.get<T>(nh);
+            Part<T> *qstage = hs.get<Part<T>>(nh);
             split_scatter_kernel<T><<<(unsigned)nblocks, kSplitThreads, 0, s>>>(heavy_rows, nheavy, blkbase, hbase, hbits,
-                                                                              nstretch, io.row_off, base, colbits, io.pcol,
-                                                                              io.pval, ghist, qcol, qval);
+                                                                              nstretch, io.row_off, base, colbits, io.stage,
+                                                                              ghist, qstage);
             uint64_t *vrow_off = hs.get<uint64_t>(nvirt + 1);
             split_vrows_kernel<<<grid_for(nvirt + 1, 256), 256, 0, s>>>(nheavy, vbase, hbase, nstretch, ghist, nvirt, nh, vrow_off);
             // merge the segments into a temporary CSR-like output
@@ -254,9 +255,10 @@ static void merge_rows(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO<
             int64_t *vptr = (int64_t *)hs.get<uint64_t>(nvirt + 1);
             uint64_t *lvl_out = hs.get<uint64_t>(2);
             OSP_HIP(hipMemsetAsync(lvl_out, 0, 2 * sizeof(uint64_t), s));
-            MergeIO<T> sub{qcol, qval, vrow_off, 0, nvirt, 0, vptr, tcol, tval, lvl_out, lvl_out + 1};
+            MergeIO<T> sub{qstage, vrow_off, 0, nvirt, 0, vptr, tcol, tval, lvl_out, lvl_out + 1};
             merge_rows<T>(ctx, res, tm, sub, colbits, false);
             split_rows_done_kernel<<<grid_for(nheavy, 256), 256, 0, s>>>(heavy_rows, nheavy, vbase, vptr, heavy_nnz, heavy_src);
+            hcopy_stage = nullptr;
             hcopy_col = tcol;
             hcopy_val = tval;
         } else {
@@ -267,17 +269,17 @@ static void merge_rows(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO<
             uint32_t *poss[2] = {hs.get<uint32_t>(nh), hs.get<uint32_t>(nh)};
             uint32_t *hist = hs.get<uint32_t>(sort_hist_entries(nh));
             uint32_t *hist_tmp = hs.get<uint32_t>(scan_scratch_entries(sort_hist_entries(nh)));
-            heavy_fill_kernel<<<grid_for(nh, 256), 256, 0, s>>>(heavy_rows, hoff, nheavy, io.row_off, base, colbits, io.pcol, nh,
-                                                                keys[0], poss[0]);
+            heavy_fill_kernel<<<grid_for(nh, 256), 256, 0, s>>>(heavy_rows, hoff, nheavy, io.row_off, base, colbits,
+                                                                (const char *)io.stage, (uint32_t)sizeof(Part<T>), nh, keys[0], poss[0]);
             const int nbits = colbits + bits_for(nheavy);
             const int cur = device_radix_sort_pairs<uint64_t>(keys, poss, nh, nbits, hist, hist_tmp, s);
             T *sorted_val = hs.get<T>(nh);
-            heavy_gather_kernel<T><<<grid_for(nh, 256), 256, 0, s>>>(poss[cur], io.pval, nh, sorted_val);
+            heavy_gather_kernel<T><<<grid_for(nh, 256), 256, 0, s>>>(poss[cur], io.stage, nh, sorted_val);
             uint64_t *headscan = hs.get<uint64_t>(nh + 1);
             uint64_t *headscan_tmp = hs.get<uint64_t>(scan_scratch_entries(nh));
             device_exclusive_scan<HeavyHeadFlag, uint64_t>(HeavyHeadFlag{keys[cur]}, nh, headscan, headscan_tmp, s);
             heavy_reduce_kernel<T><<<grid_for(nh, 256), 256, 0, s>>>(keys[cur], sorted_val, headscan, nh, heavy_rows, hoff,
-                                                                     nheavy, io.row_off, base, colbits, io.pcol, io.pval);
+                                                                     nheavy, io.row_off, base, colbits, io.stage);
             heavy_rows_kernel<<<grid_for(nheavy, 256), 256, 0, s>>>(heavy_rows, hoff, nheavy, headscan, heavy_nnz);
             heavy_src_inplace_kernel<<<grid_for(nheavy, 256), 256, 0, s>>>(heavy_rows, nheavy, io.row_off, base, heavy_src);
         }
@@ -293,14 +295,14 @@ static void merge_rows(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO<
             throw Error(OSP_ERR_ARG, "merge-by-runs build is only wired for bench_merge");
         else
             merge_tiles_kernel<T, kMergeThreads><<<std::min<uint32_t>(ntiles, ctx->merge_grid), kMergeThreads, 0, s>>>(
-                desc, ntiles, r1, io.row_off, base, colbits, io.pcol, io.pval, heavy_nnz, tile_status, ticket, io.out_in,
+                desc, ntiles, r1, io.row_off, base, colbits, io.stage, heavy_nnz, tile_status, ticket, io.out_in,
                 io.c_rowptr, io.c_col, io.c_val, io.out_out);
         tm.end(PH_MERGE_K);
         res->info.merge_launches++;
     }
     if (nheavy)
-        heavy_copy_kernel<T><<<nheavy * 8u, 256, 0, s>>>(heavy_rows, nheavy, heavy_src, heavy_nnz, io.c_rowptr, hcopy_col,
-                                                             hcopy_val, io.c_col, io.c_val);
+        heavy_copy_kernel<T><<<nheavy * 8u, 256, 0, s>>>(heavy_rows, nheavy, heavy_src, heavy_nnz, io.c_rowptr, hcopy_stage,
+                                                         hcopy_col, hcopy_val, io.c_col, io.c_val);
     OSP_HIP(hipGetLastError());  // a rejected launch must not pass silently
 }
 
@@ -362,8 +364,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         max_panel = std::max(max_panel, cnt);
         max_rows_panel = std::max(max_rows_panel, bounds[p + 1] - bounds[p]);
     }
-    uint32_t *pcol = sc.get<uint32_t>(max_panel);
-    T *pval = sc.get<T>(max_panel);
+    Part<T> *stage = sc.get<Part<T>>(max_panel);
     uint64_t *scan_tmp = sc.get<uint64_t>(scan_scratch_entries(std::max<uint64_t>(M + 1, 16)));
     uint64_t *out_nnz = sc.get<uint64_t>((uint64_t)npanels + 1);  // nnz written before panel p
     OSP_HIP(hipMemsetAsync(out_nnz, 0, sizeof(uint64_t), s));
@@ -387,11 +388,11 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         const uint64_t count = (npanels == 1) ? P : h_off[r1] - base;
         // ---- multiply (or scatter of CSR parts) ----
         tm.begin(PH_MUL);
-        if (count) prod.produce(r0, r1, npanels == 1, base, count, pcol, pval, tm);
+        if (count) prod.produce(r0, r1, npanels == 1, base, count, stage, tm);
         tm.end(PH_MUL);
         // ---- merge ----
         tm.begin(PH_MERGE);
-        MergeIO<T> io{pcol, pval, d_row_off, r0, r1, base, res->rowptr, c_col, c_val, out_nnz + p, out_nnz + p + 1};
+        MergeIO<T> io{stage, d_row_off, r0, r1, base, res->rowptr, c_col, c_val, out_nnz + p, out_nnz + p + 1};
         merge_rows<T>(ctx, res, tm, io, colbits, true);
         tm.end(PH_MERGE);
     }
@@ -423,8 +424,8 @@ template <class T> struct OuterProducer : Producer<T> {
     uint64_t k0, k1; int64_t e0;
     const uint64_t *chunk_off;
     int64_t *a_start; uint32_t *a_cnt; uint64_t *prod; uint64_t *prod_off; uint64_t *scan_tmp;
-    void produce(uint64_t r0, uint64_t r1, bool whole, uint64_t base, uint64_t count, uint32_t *pcol,
-                 T *pval, PhaseTimer &tm) override {
+    void produce(uint64_t r0, uint64_t r1, bool whole, uint64_t base, uint64_t count, Part<T> *stage,
+                 PhaseTimer &tm) override {
         hipStream_t s = ctx->stream;
         const uint64_t nk = k1 - k0;
         panel_columns_kernel<<<grid_for(nk, 256), 256, 0, s>>>(a_colptr, a_rowidx, b_rowptr, k0, nk, (uint32_t)r0, r1,
@@ -433,8 +434,7 @@ template <class T> struct OuterProducer : Producer<T> {
         const uint64_t nblocks = (count + kMulPerBlock - 1) / kMulPerBlock;
         tm.begin(PH_MUL_K);
         multiply_kernel<T><<<(unsigned)nblocks, kMulThreads, 0, s>>>(a_vals, b_colidx, b_vals, b_rowptr, chunk_off, e0,
-                                                                     a_start, a_cnt, prod_off, k0, nk, count, base, pcol,
-                                                                     pval);
+                                                                     a_start, a_cnt, prod_off, k0, nk, count, base, stage);
         tm.end(PH_MUL_K);
         res->info.multiply_launches++;
     }
@@ -445,11 +445,10 @@ template <class T> struct PartsProducer : Producer<T> {
     const int64_t *const *d_rowptrs; const uint32_t *const *d_colidxs; const T *const *d_valss;
     int nparts;
     const uint64_t *row_off;
-    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, uint32_t *pcol, T *pval,
-                 PhaseTimer &) override {
+    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &) override {
         const uint64_t nr = r1 - r0;
         parts_scatter_kernel<T><<<grid_for(nr * kWave, 256), 256, 0, ctx->stream>>>(d_rowptrs, d_colidxs, d_valss, nparts,
-                                                                                    r0, r1, row_off, base, pcol, pval);
+                                                                                    r0, r1, row_off, base, stage);
     }
 };
 

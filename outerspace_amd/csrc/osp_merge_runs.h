@@ -41,8 +41,8 @@ template <class T, int NT, int ABL = 0>
 __global__ __launch_bounds__(NT) void merge_runs_kernel(
     const uint32_t *__restrict__ tile_rows, uint32_t ntiles, uint64_t r_end,
     const uint64_t *__restrict__ row_off, uint64_t base, const uint32_t *__restrict__ arow,
-    const uint64_t *__restrict__ chunk_start, const uint32_t *__restrict__ pcol,
-    const T *__restrict__ pval, const uint32_t *__restrict__ heavy_nnz, uint64_t *tile_status,
+    const uint64_t *__restrict__ chunk_start, const Part<T> *__restrict__ stage,
+    const uint32_t *__restrict__ heavy_nnz, uint64_t *tile_status,
     uint32_t *ticket, const uint64_t *__restrict__ out_base_p, int64_t *__restrict__ c_rowptr,
     uint32_t *__restrict__ c_col, T *__restrict__ c_val, uint64_t *__restrict__ out_end_p) {
     __shared__ RunsSmem<T, NT> sm;
@@ -94,9 +94,10 @@ __global__ __launch_bounds__(NT) void merge_runs_kernel(
         const uint32_t c = lo;
         lo = 0; hi = nr;           // row of c: last r < nr with cfirst[r] <= c
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sm.cfirst[mid] <= c) lo = mid; else hi = mid; }
-        sm.key[0][p] = pcol[s + p];
+        const Part<T> pp = stage[s + p];
+        sm.key[0][p] = pp.col;
         sm.pay[0][p] = p | ((c - sm.cfirst[lo]) << 12) | (lo << 24);
-        sm.val[p] = pval[s + p];
+        sm.val[p] = pp.val;
     }
     __syncthreads();
     int levels = 0;

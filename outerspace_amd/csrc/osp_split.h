@@ -65,14 +65,16 @@ __device__ __forceinline__ SplitJob split_job(const uint32_t *rows, uint32_t nhe
 // histogram of one stretch over the row's segments -> ghist[hbase + seg * nst + st]
 __global__ __launch_bounds__(kSplitThreads) void split_count_kernel(
     const uint32_t *rows, uint32_t nheavy, const uint64_t *blkbase, const uint64_t *hbase, const uint8_t *hbits,
-    const uint32_t *nstretch, const uint64_t *row_off, uint64_t base, int colbits, const uint32_t *pcol, uint32_t *ghist) {
+    const uint32_t *nstretch, const uint64_t *row_off, uint64_t base, int colbits, const char *stage, uint32_t rec_bytes,
+    uint32_t *ghist) {
     __shared__ uint32_t hist[1 << kSplitMaxBits];
     const SplitJob j = split_job(rows, nheavy, blkbase, hbase, hbits, nstretch, row_off, base);
     const uint32_t nseg = 1u << j.b;
     for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) hist[d] = 0;
     __syncthreads();
     const int sh = colbits - (int)j.b;
-    for (uint64_t i = j.beg + threadIdx.x; i < j.end; i += kSplitThreads) atomicAdd(&hist[pcol[i] >> sh], 1u);
+    for (uint64_t i = j.beg + threadIdx.x; i < j.end; i += kSplitThreads)
+        atomicAdd(&hist[*(const uint32_t *)(stage + i * rec_bytes) >> sh], 1u);
     __syncthreads();
     for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) ghist[j.hbase + (uint64_t)d * j.nst + j.st] = hist[d];
 }
@@ -96,8 +98,8 @@ __device__ __forceinline__ void wave_match_bits(unsigned digit, int bits, bool v
 template <class T>
 __global__ __launch_bounds__(kSplitThreads) void split_scatter_kernel(
     const uint32_t *rows, uint32_t nheavy, const uint64_t *blkbase, const uint64_t *hbase, const uint8_t *hbits,
-    const uint32_t *nstretch, const uint64_t *row_off, uint64_t base, int colbits, const uint32_t *pcol,
-    const T *pval, const uint32_t *goffs, uint32_t *qcol, T *qval) {
+    const uint32_t *nstretch, const uint64_t *row_off, uint64_t base, int colbits, const Part<T> *stage,
+    const uint32_t *goffs, Part<T> *qstage) {
     constexpr int NW = kSplitThreads / kWave;
     constexpr int ITERS = kSplitStretch / kSplitThreads;  // 16 wave iterations per wave span
     __shared__ uint16_t cnt[NW][1 << kSplitMaxBits];
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(kSplitThreads) void split_scatter_kernel(
         const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
         const bool valid = i < j.end;
         kc[it] = 0; kv[it] = 0;
-        if (valid) { kc[it] = pcol[i]; kv[it] = pval[i]; }
+        if (valid) { const Part<T> pp = stage[i]; kc[it] = pp.col; kv[it] = pp.val; }
     }
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
@@ -150,8 +152,7 @@ __global__ __launch_bounds__(kSplitThreads) void split_scatter_kernel(
         if (i < j.end) {
             const unsigned d = kc[it] >> sh;
             const uint32_t dst = boff[d] + cnt[w][d] + rk[it];
-            qcol[dst] = kc[it];
-            qval[dst] = kv[it];
+            qstage[dst] = Part<T>{kc[it], kv[it]};
         }
     }
 }

@@ -11,6 +11,11 @@
 using namespace osp;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+Part<double> *g_stage;
+__global__ void pack_kernel(const uint32_t *pcol, const double *pval, uint64_t n, Part<double> *stage) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) stage[i] = Part<double>{pcol[i], pval[i]};
+}
 __global__ void fill_kernel(uint32_t *pcol, double *pval, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -45,7 +50,7 @@ float run_runs(uint32_t *tile_rows, uint32_t ntiles, uint64_t M, uint64_t *row_o
     CK(hipMemsetAsync(ticket, 0, 4, 0));
     CK(hipMemsetAsync(outn, 0, 16, 0));
     CK(hipEventRecord(a, 0));
-    merge_runs_kernel<double, NT, ABL><<<ntiles, NT, 0, 0>>>(tile_rows, ntiles, M, row_off, 0, g_arow, g_chunk_start, pcol, pval, heavy,
+    merge_runs_kernel<double, NT, ABL><<<ntiles, NT, 0, 0>>>(tile_rows, ntiles, M, row_off, 0, g_arow, g_chunk_start, g_stage, heavy,
                                                              status, ticket, outn, rowptr, ccol, cval, outn + 1);
     CK(hipEventRecord(b, 0));
     CK(hipEventSynchronize(b));
@@ -73,7 +78,7 @@ float run(uint32_t *tile_rows, uint32_t ntiles, uint64_t M, uint64_t *row_off, u
     CK(hipMemsetAsync(ticket, 0, 4, 0));
     CK(hipMemsetAsync(outn, 0, 16, 0));
     CK(hipEventRecord(a, 0));
-    merge_tiles_kernel<double, NT, ABL><<<ntiles < g_grid ? ntiles : g_grid, NT, 0, 0>>>(g_desc, ntiles, M, row_off, 0, 22, pcol, pval, heavy, status,
+    merge_tiles_kernel<double, NT, ABL><<<ntiles < g_grid ? ntiles : g_grid, NT, 0, 0>>>(g_desc, ntiles, M, row_off, 0, 22, g_stage, heavy, status,
                                                               ticket, outn, rowptr, ccol, cval, outn + 1);
     CK(hipEventRecord(b, 0));
     CK(hipEventSynchronize(b));
@@ -102,6 +107,8 @@ int main(int argc, char **argv) {
     arow_kernel<<<(unsigned)((M + 256) / 256), 256>>>(g_arow, M, rowlen / clen);
     rows_kernel<<<(unsigned)((M + 256) / 256), 256>>>(row_off, M, rowlen);
     tiles_kernel<<<(ntiles + 255) / 256, 256>>>(tile_rows, ntiles, rpt);
+    CK(hipMalloc(&g_stage, P * sizeof(Part<double>)));
+    pack_kernel<<<(unsigned)((P + 255) / 256), 256>>>(pcol, pval, P, g_stage);
     CK(hipMalloc(&g_desc, (uint64_t)ntiles * sizeof(TileDesc)));
     tile_desc_kernel<3072><<<(ntiles + 255) / 256, 256>>>(tile_rows, ntiles, M, row_off, 0, g_desc);
     if (getenv("GRID")) g_grid = atoi(getenv("GRID"));
