@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -62,17 +63,24 @@ struct Context {
     }
     void *alloc(size_t bytes) {
         size_t b = bucket(bytes ? bytes : 1);
-        auto it = free_list.find(b);
+        // best fit among pooled blocks: anything from b to 1.5 b is reused (buffer sizes drift from panel to
+        // panel and from call to call; hipMalloc / hipFree of multi-GB blocks cost far more than the slack)
+        auto it = free_list.lower_bound(b);
         void *p = nullptr;
-        if (it != free_list.end()) {
+        if (it != free_list.end() && it->first <= b + b / 2) {
             p = it->second;
+            b = it->first;
             free_list.erase(it);
             pooled_bytes -= b;
         } else {
             hipError_t e = hipMalloc(&p, b);
-            if (e != hipSuccess) {
+            while (e != hipSuccess && !free_list.empty()) {
+                // out of memory: give the largest pooled blocks back until the request fits
                 (void)hipGetLastError();
-                trim();
+                auto big = std::prev(free_list.end());
+                (void)hipFree(big->second);
+                pooled_bytes -= big->first;
+                free_list.erase(big);
                 e = hipMalloc(&p, b);
             }
             if (e != hipSuccess) {
@@ -221,6 +229,10 @@ static void merge_rows(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO<
         device_exclusive_scan<HeavyLen, uint64_t>(HeavyLen{heavy_rows, io.row_off}, nheavy, hoff, hscan_tmp, s);
         const uint64_t nh = d2h(hoff + nheavy, s);
         if (nh >= 0xffffffffull) throw Error(OSP_ERR_CAPACITY, "long rows of one panel exceed 2^32 partial products");
+        if (getenv("OSP_VERBOSE"))
+            fprintf(stderr, "[osp]   %s: rows [%llu,%llu) tiles %u, %u long rows with %llu partial products\n",
+                    allow_split ? "panel" : "segments", (unsigned long long)r0, (unsigned long long)r1, ntiles, nheavy,
+                    (unsigned long long)nh);
         if (allow_split) {
             // ---- one stable split by column range, then the same tile merge on the segments ----
             res->info.heavy_rows += nheavy;
@@ -324,17 +336,33 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         res->info.nnz_c = 0;
         return;
     }
+    // ---- final CSR arrays at an upper bound: nnz(C) <= sum_i min(U_i, N) -------------------------------
+    const uint64_t E = 4 + sizeof(T);
+    uint64_t cap_c;
+    {
+        Scratch us(ctx);
+        uint64_t *ub = us.get<uint64_t>(M + 1);
+        uint64_t *ub_tmp = us.get<uint64_t>(scan_scratch_entries(M + 1));
+        device_exclusive_scan<RowUpperBound, uint64_t>(RowUpperBound{d_row_off, N}, M, ub, ub_tmp, s);
+        cap_c = d2h(ub + M, s);
+    }
+    res->colidx = (uint32_t *)ctx->alloc(std::max<uint64_t>(cap_c, 1) * sizeof(uint32_t));
+    res->vals = ctx->alloc(std::max<uint64_t>(cap_c, 1) * sizeof(T));
+    uint32_t *c_col = res->colidx;
+    T *c_val = (T *)res->vals;
     // ---- panels: consecutive rows whose partial products fit the staging capacity --------------
+    // What is left after the output is shared by the staging buffer and, for long rows, the split
+    // buffer and its temporary output (each up to one panel): budget a third of it, with slack.
     size_t free_b = 0, total_b = 0;
     OSP_HIP(hipMemGetInfo(&free_b, &total_b));
     free_b += ctx->pooled_bytes;
-    const uint64_t E = 4 + sizeof(T);
     uint64_t cap = cap_cfg;
-    if (cap == 0) {
-        // staging + merged output + heavy-path scratch must coexist: budget ~30 % of free memory
-        cap = std::max<uint64_t>((uint64_t)(free_b * 0.30 / E), 1ull << 20);
-    }
+    if (cap == 0) cap = std::max<uint64_t>((uint64_t)(free_b * 0.85 / (3.3 * E)), 1ull << 20);
     cap = std::min<uint64_t>(cap, 0xfffffff0ull);  // staging positions are u32
+    if (getenv("OSP_VERBOSE"))
+        fprintf(stderr, "[osp] M=%llu N=%llu P=%llu nnzC<=%llu (%.1f GB) free %.1f GB -> staging capacity %llu partial products (%.1f GB)\n",
+                (unsigned long long)M, (unsigned long long)N, (unsigned long long)P, (unsigned long long)cap_c, cap_c * E / 1e9,
+                free_b / 1e9, (unsigned long long)cap, cap * E / 1e9);
     std::vector<uint64_t> bounds{0};
     std::vector<uint64_t> h_off;
     if (P <= cap) {
@@ -365,22 +393,8 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         max_rows_panel = std::max(max_rows_panel, bounds[p + 1] - bounds[p]);
     }
     Part<T> *stage = sc.get<Part<T>>(max_panel);
-    uint64_t *scan_tmp = sc.get<uint64_t>(scan_scratch_entries(std::max<uint64_t>(M + 1, 16)));
     uint64_t *out_nnz = sc.get<uint64_t>((uint64_t)npanels + 1);  // nnz written before panel p
     OSP_HIP(hipMemsetAsync(out_nnz, 0, sizeof(uint64_t), s));
-
-    // final CSR arrays at an upper bound: nnz(C) <= sum_i min(U_i, N)
-    uint64_t cap_c;
-    {
-        Scratch us(ctx);
-        uint64_t *ub = us.get<uint64_t>(M + 1);
-        device_exclusive_scan<RowUpperBound, uint64_t>(RowUpperBound{d_row_off, N}, M, ub, scan_tmp, s);
-        cap_c = d2h(ub + M, s);
-    }
-    res->colidx = (uint32_t *)ctx->alloc(std::max<uint64_t>(cap_c, 1) * sizeof(uint32_t));
-    res->vals = ctx->alloc(std::max<uint64_t>(cap_c, 1) * sizeof(T));
-    uint32_t *c_col = res->colidx;
-    T *c_val = (T *)res->vals;
 
     for (uint32_t p = 0; p < npanels; p++) {
         const uint64_t r0 = bounds[p], r1 = bounds[p + 1];
