@@ -29,7 +29,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scale", type=int, default=22)
     ap.add_argument("--edge-factor", type=int, default=16)
-    ap.add_argument("--rmat", default="uniform", help="uniform | mild | g500 | a,b,c,d")
+    ap.add_argument("--rmat", default="mild",
+                    help="R-MAT (a,b,c,d): mild=(.45,.22,.22,.11) [default: skewed, and C still fits one GPU's HBM] | "
+                         "uniform=(.25,.25,.25,.25) | g500=(.57,.19,.19,.05) [scale-22 needs ~840 GB for C] | a,b,c,d")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--dtype", default="f64", choices=["f32", "f64"])
     ap.add_argument("--partial-capacity", type=int, default=0)
@@ -221,7 +223,8 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"k-sharded over {world} GPUs + RCCL all-to-all of partial CSRs"},
             "gflops": 2 * P / (ms_step * 1e-3) / 1e9, "partials_per_s": P / (ms_step * 1e-3),
             "phases_ms": {k: mean(k) for k in ("ms_symbolic", "ms_multiply", "ms_merge", "ms_compact", "ms_total")},
-            "panels": info["panels"], "heavy_rows": info["heavy_rows"], "heavy_partials": info["heavy_partials"],
+            "panels": info["panels"], "long_rows_split": info["heavy_rows"], "long_row_partials": info["heavy_partials"],
+            "segments_global_sorted": info["sorted_segments"], "segment_partials_global_sorted": info["sorted_partials"],
             "roofline": roof,
         }
         if world > 1:

@@ -263,3 +263,90 @@ def test_properties_at_scale(ctx):
     assert res.nnz == (A @ A).nnz  # values are positive: no cancellation, scipy structure agrees
     res2 = ctx.spgemm_csc_csr(n, n, n, acsc[0], acsc[1], 2.0 * acsc[2], *bcsr)
     assert np.array_equal(res2.colidx, ci) and np.array_equal(res2.vals, 2.0 * cv)
+
+
+def test_cli_reference_call_shape(golden_dir, tmp_path):
+    """`osp_spgemm A.mtx B.mtx` mirrors `./simulator A.mtx B.mtx` (SimSpGEMM.cpp:819-894)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "outerspace_amd", "osp_spgemm")
+    out = tmp_path / "c.mtx"
+    r = subprocess.run([exe, os.path.join(golden_dir, "c1_A.mtx"), os.path.join(golden_dir, "c1_B.mtx"), "--out", str(out)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "NCol = 64, NRow = 64, NNZ = 410" in r.stdout          # the reference's (swapped) labels, :866
+    assert "mul flops ref = 2692" in r.stdout                      # :891
+    from outerspace_amd import spgemm as S
+    g = load(golden_dir, "c1_expected.npz")
+    nrow, ncol, rr, cc, vv = S.read_mtx(str(out))
+    assert (nrow, ncol) == (64, 64) and np.array_equal(rr, g["rows_float32"]) and np.array_equal(cc, g["cols_float32"])
+    assert np.allclose(vv, g["vals_float32"], rtol=1e-5, atol=0)
+    # duplicate coordinate: the reference dies with an uncaught throw(233)
+    dup = tmp_path / "dup.mtx"
+    dup.write_text("%%MatrixMarket matrix coordinate real general\n2 2 3\n1 1 1.0\n2 2 2.0\n2 2 3.0\n")
+    r = subprocess.run([exe, str(dup), str(dup)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 233 and "233" in r.stderr
+
+
+def test_device_pointer_api_with_torch(ctx, port):
+    """Operands resident in HBM (torch tensors), result borrowed in place -- the bench / multi-GPU path."""
+    import torch
+    from outerspace_amd import spgemm as S
+    from outerspace_amd.distributed import _as_tensor
+    n, rows, cols, vals = gen.rmat_coo(12, 8, "mild", seed=9)
+    acsc = S.coo_to_csc(n, rows, cols, vals)
+    bcsr = S.coo_to_csr(n, rows, cols, vals)
+    dev = torch.device("cuda", 0)
+    t = [torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).to(dev) for a in (*acsc, *bcsr)]
+    res = ctx.spgemm_csc_csr_device(np.float64, n, n, n, [x.data_ptr() for x in t], validate=True)
+    want = port.spgemm(n, n, n, *acsc, *bcsr)
+    rp, ci, va = res.device_ptrs()
+    got_rp = _as_tensor(rp, n + 1, "<i8", dev, torch.int64).cpu().numpy()
+    got_ci = _as_tensor(ci, res.nnz, "<i4", dev, torch.int32).cpu().numpy().view(np.uint32)
+    got_va = _as_tensor(va, res.nnz, "<f8", dev, torch.float64).cpu().numpy()
+    assert np.array_equal(got_rp, want["rowptr"]) and np.array_equal(got_ci, want["colidx"]) and np.array_equal(got_va, want["vals"])
+
+
+def test_power_law_web_graph_shape(ctx):
+    """BASELINE configs[1] shape (web-Google-like: power-law degrees, pattern values = 1.0), reduced size,
+    against scipy: structure exact, values exact (small integers in f64)."""
+    import scipy.sparse as sp
+    from outerspace_amd import spgemm as S
+    rng = np.random.default_rng(5)
+    n = 60000
+    deg = np.minimum((rng.pareto(1.2, n) + 1).astype(np.int64) * 2, 3000)
+    rows = np.repeat(np.arange(n), deg)
+    cols = (rng.pareto(0.9, len(rows)) * 50).astype(np.int64) % n      # a few very popular targets
+    key = np.unique(rows * n + cols)
+    rows, cols = (key // n).astype(np.uint32), (key % n).astype(np.uint32)
+    vals = np.ones(len(key))                                             # pattern file -> 1.0 (SimSpGEMM.cpp:92-93)
+    res = ctx.spgemm_csc_csr(n, n, n, *S.coo_to_csc(n, rows, cols, vals), *S.coo_to_csr(n, rows, cols, vals))
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+    want = (A @ A).tocsr()
+    want.sort_indices()
+    assert np.array_equal(res.rowptr, want.indptr) and np.array_equal(res.colidx, want.indices.astype(np.uint32))
+    assert np.array_equal(res.vals, want.data)
+    assert res.info["heavy_rows"] > 0
+
+
+def test_merge_parts_with_empty_and_single(ctx):
+    from outerspace_amd import spgemm as S
+    import scipy.sparse as sp
+    rng = np.random.default_rng(1)
+    mats = [sp.random(50, 40, 0.1, random_state=rng, format="csr"), sp.csr_matrix((50, 40)),
+            sp.random(50, 40, 0.3, random_state=rng, format="csr")]
+    for m in mats:
+        m.sort_indices()
+    parts = [(m.indptr.astype(np.int64), m.indices.astype(np.uint32), m.data) for m in mats]
+    got = ctx.merge_csr_parts(50, 40, parts).to_scipy()
+    want = mats[0] + mats[1] + mats[2]
+    assert abs(got - want).max() < 1e-12 and got.nnz == want.nnz
+    one = ctx.merge_csr_parts(50, 40, parts[2:])
+    assert np.array_equal(one.rowptr, parts[2][0]) and np.array_equal(one.colidx, parts[2][1]) and np.array_equal(one.vals, parts[2][2])
+
+
+def test_f32_skewed_bit_exact(ctx, port):
+    n, rows, cols, vals = gen.rmat_coo(13, 16, "g500", seed=4, dtype=np.float32)
+    got, want = run_both(ctx, port, n, n, n, (rows, cols, vals), (rows, cols, vals), np.float32)
+    assert got.info["heavy_rows"] > 0
+    assert_same(got, want)
