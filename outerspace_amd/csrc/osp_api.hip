@@ -177,7 +177,6 @@ template <class T> struct Producer {
 };
 
 // ---- rows of partial products -> merged rows -------------------------------------------------------
-// `rows` are real output rows (level 0) or the column-range segments of split long rows (level 1).
 template <class T> struct MergeIO {
     Part<T> *stage;                      // partial products of rows [r0,r1), addressed row_off[r] - base
     const uint64_t *row_off; uint64_t r0, r1, base;
@@ -185,136 +184,161 @@ template <class T> struct MergeIO {
     const uint64_t *out_in; uint64_t *out_out;    // entries written before / after this call (device)
 };
 
+struct TilePlan {
+    uint32_t *tile_rows = nullptr;  // first row of every tile
+    uint32_t ntiles = 0;
+    uint32_t *long_rows = nullptr;  // rows with more partial products than one tile
+    uint32_t nlong = 0;
+};
+
+// Greedy tile packing (coarse blocks of ~8 tiles, one walker thread per block) + the list of long rows.
+static TilePlan plan_tiles(Context *ctx, Scratch &sc, const uint64_t *row_off, uint64_t r0, uint64_t r1, uint64_t base,
+                           uint32_t cap, uint32_t max_rows, const uint8_t *force_start) {
+    hipStream_t s = ctx->stream;
+    const uint64_t nr = r1 - r0;
+    TilePlan pl;
+    uint32_t *flag_scan = sc.get<uint32_t>(nr + 1);
+    uint32_t *tmp_rows = sc.get<uint32_t>(nr + 1);
+    uint64_t *scan_tmp = sc.get<uint64_t>(scan_scratch_entries(std::max<uint64_t>(nr + 1, 16)));
+    CoarseStartFlag csf{row_off, r0, base, 8ull * cap, force_start};
+    device_exclusive_scan<CoarseStartFlag, uint32_t>(csf, nr, flag_scan, (uint32_t *)scan_tmp, s);
+    compact_flagged_kernel<CoarseStartFlag><<<grid_for(nr, 256), 256, 0, s>>>(csf, flag_scan, nr, r0, tmp_rows);
+    const uint32_t ncb = d2h(flag_scan + nr, s);
+    uint32_t *cb_cnt = sc.get<uint32_t>((uint64_t)ncb + 1);
+    tile_walk_kernel<<<grid_for(ncb, 128), 128, 0, s>>>(tmp_rows, ncb, r1, row_off, cap, max_rows, nullptr, cb_cnt, nullptr);
+    device_exclusive_scan<LoadU32, uint32_t>(LoadU32{cb_cnt}, ncb, cb_cnt, (uint32_t *)scan_tmp, s);
+    pl.ntiles = d2h(cb_cnt + ncb, s);
+    pl.tile_rows = sc.get<uint32_t>((uint64_t)pl.ntiles + 1);
+    tile_walk_kernel<<<grid_for(ncb, 128), 128, 0, s>>>(tmp_rows, ncb, r1, row_off, cap, max_rows, cb_cnt, nullptr, pl.tile_rows);
+    HeavyRowFlag hrf{row_off, r0, cap};
+    device_exclusive_scan<HeavyRowFlag, uint32_t>(hrf, nr, flag_scan, (uint32_t *)scan_tmp, s);
+    pl.long_rows = sc.get<uint32_t>(nr + 1);
+    compact_flagged_kernel<HeavyRowFlag><<<grid_for(nr, 256), 256, 0, s>>>(hrf, flag_scan, nr, r0, pl.long_rows);
+    pl.nlong = d2h(flag_scan + nr, s);
+    return pl;
+}
+
+// One panel: tiles of rows, long rows split into column-range segments whose tiles take the long row's
+// place in ONE offset chain, so every merged entry is written once, straight to the final CSR.
 template <class T>
-static void merge_rows(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO<T> &io, int colbits, bool allow_split) {
+static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO<T> &io, int colbits) {
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
-    constexpr uint32_t kCap = kMergeByRuns ? (uint32_t)RunCap<T>::value : (uint32_t)TileCap<T>::value;
-    const uint32_t max_rows = kMergeByRuns ? (uint32_t)kTileMaxRows
-                                           : (uint32_t)std::min<uint64_t>(kTileMaxRows, colbits >= 32 ? 1ull : (1ull << (32 - colbits)));
-    const uint64_t r0 = io.r0, r1 = io.r1, nr = r1 - r0, base = io.base;
-    uint32_t *flag_scan = sc.get<uint32_t>(nr + 1);
-    uint32_t *tile_rows = sc.get<uint32_t>(nr + 1);
-    uint32_t *heavy_rows = sc.get<uint32_t>(nr + 1);
-    uint32_t *heavy_nnz = sc.get<uint32_t>(nr + 1) - r0;  // indexed by absolute row id
-    uint64_t *scan_tmp = sc.get<uint64_t>(scan_scratch_entries(std::max<uint64_t>(nr + 1, 16)));
-    uint32_t *ticket = sc.get<uint32_t>(1);
+    constexpr uint32_t kCap = (uint32_t)TileCap<T>::value;
+    const uint32_t max_rows = (uint32_t)std::min<uint64_t>(kTileMaxRows, colbits >= 32 ? 1ull : (1ull << (32 - colbits)));
+    const uint64_t r0 = io.r0, r1 = io.r1, base = io.base;
+    const TilePlan p0 = plan_tiles(ctx, sc, io.row_off, r0, r1, base, kCap, max_rows, nullptr);
+    res->info.light_tiles += p0.ntiles - p0.nlong;
 
-    // greedy tile packing: coarse blocks of ~8 tiles, one walker thread per block
-    CoarseStartFlag csf{io.row_off, r0, base, 8ull * kCap};
-    device_exclusive_scan<CoarseStartFlag, uint32_t>(csf, nr, flag_scan, (uint32_t *)scan_tmp, s);
-    compact_flagged_kernel<CoarseStartFlag><<<grid_for(nr, 256), 256, 0, s>>>(csf, flag_scan, nr, r0, heavy_rows /*tmp*/);
-    const uint32_t ncb = d2h(flag_scan + nr, s);
-    uint32_t *cb_rows = sc.get<uint32_t>(ncb), *cb_cnt = sc.get<uint32_t>((uint64_t)ncb + 1);
-    OSP_HIP(hipMemcpyAsync(cb_rows, heavy_rows, (uint64_t)ncb * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-    tile_walk_kernel<<<grid_for(ncb, 128), 128, 0, s>>>(cb_rows, ncb, r1, io.row_off, kCap, max_rows, nullptr, cb_cnt, nullptr);
-    device_exclusive_scan<LoadU32, uint32_t>(LoadU32{cb_cnt}, ncb, cb_cnt, (uint32_t *)scan_tmp, s);
-    const uint32_t ntiles = d2h(cb_cnt + ncb, s);
-    tile_walk_kernel<<<grid_for(ncb, 128), 128, 0, s>>>(cb_rows, ncb, r1, io.row_off, kCap, max_rows, cb_cnt, nullptr, tile_rows);
-    HeavyRowFlag hrf{io.row_off, r0, kCap};
-    device_exclusive_scan<HeavyRowFlag, uint32_t>(hrf, nr, flag_scan, (uint32_t *)scan_tmp, s);
-    compact_flagged_kernel<HeavyRowFlag><<<grid_for(nr, 256), 256, 0, s>>>(hrf, flag_scan, nr, r0, heavy_rows);
-    const uint32_t nheavy = d2h(flag_scan + nr, s);
-    if (allow_split) res->info.light_tiles += ntiles - nheavy;
-
-    Scratch hs(ctx);  // long-row buffers live until their entries have been copied into place
-    uint64_t *heavy_src = nullptr;
-    const Part<T> *hcopy_stage = io.stage;  // where the long rows' merged entries are copied from
-    const uint32_t *hcopy_col = nullptr;
-    const T *hcopy_val = nullptr;
-    if (nheavy) {
-        heavy_src = hs.get<uint64_t>(nheavy);
-        uint64_t *hoff = hs.get<uint64_t>((uint64_t)nheavy + 1);
-        uint64_t *hscan_tmp = hs.get<uint64_t>(scan_scratch_entries(nheavy));
-        device_exclusive_scan<HeavyLen, uint64_t>(HeavyLen{heavy_rows, io.row_off}, nheavy, hoff, hscan_tmp, s);
-        const uint64_t nh = d2h(hoff + nheavy, s);
+    MergeLevels<T> lv{};
+    lv.stage[0] = io.stage; lv.row_off[0] = io.row_off; lv.base[0] = base; lv.c_rowptr[0] = io.c_rowptr; lv.heavy_nnz[0] = nullptr;
+    uint32_t ntot = p0.ntiles;
+    TileDesc *desc = nullptr;
+    // level-1 state (split long rows)
+    TilePlan p1;
+    uint64_t *vbase = nullptr;
+    int64_t *vptr = nullptr;
+    uint64_t *seg_src = nullptr;   // too-long segments: where their reduced entries sit in the second buffer
+    uint32_t *seg_nnz = nullptr;
+    Part<T> *qstage = nullptr;
+    if (p0.nlong) {
+        const uint32_t nlong = p0.nlong;
+        uint64_t *hoff = sc.get<uint64_t>((uint64_t)nlong + 1);
+        uint64_t *hscan_tmp = sc.get<uint64_t>(scan_scratch_entries(nlong));
+        device_exclusive_scan<HeavyLen, uint64_t>(HeavyLen{p0.long_rows, io.row_off}, nlong, hoff, hscan_tmp, s);
+        const uint64_t nh = d2h(hoff + nlong, s);
         if (nh >= 0xffffffffull) throw Error(OSP_ERR_CAPACITY, "long rows of one panel exceed 2^32 partial products");
+        res->info.heavy_rows += nlong;
+        res->info.heavy_partials += nh;
+        // ---- one stable split by column range into the second buffer ----
+        uint8_t *hbits = sc.get<uint8_t>(nlong);
+        uint32_t *nstretch = sc.get<uint32_t>(nlong), *nseg = sc.get<uint32_t>(nlong);
+        uint64_t *nhist = sc.get<uint64_t>(nlong);
+        uint64_t *blkbase = sc.get<uint64_t>((uint64_t)nlong + 1), *hbase = sc.get<uint64_t>((uint64_t)nlong + 1);
+        vbase = sc.get<uint64_t>((uint64_t)nlong + 1);
+        split_params_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(p0.long_rows, nlong, io.row_off, colbits, hbits, nstretch, nseg, nhist);
+        device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nstretch}, nlong, blkbase, hscan_tmp, s);
+        device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nseg}, nlong, vbase, hscan_tmp, s);
+        device_exclusive_scan<LoadU64, uint64_t>(LoadU64{nhist}, nlong, hbase, hscan_tmp, s);
+        const uint64_t nblocks = d2h(blkbase + nlong, s), nvirt = d2h(vbase + nlong, s), ncell = d2h(hbase + nlong, s);
+        if (ncell >= 0xffffffffull || nblocks >= 0x7fffffffull || nvirt >= 0xffffffffull)
+            throw Error(OSP_ERR_CAPACITY, "split histogram too large");
         if (getenv("OSP_VERBOSE"))
-            fprintf(stderr, "[osp]   %s: rows [%llu,%llu) tiles %u, %u long rows with %llu partial products\n",
-                    allow_split ? "panel" : "segments", (unsigned long long)r0, (unsigned long long)r1, ntiles, nheavy,
-                    (unsigned long long)nh);
-        if (allow_split) {
-            // ---- one stable split by column range, then the same tile merge on the segments ----
-            res->info.heavy_rows += nheavy;
-            res->info.heavy_partials += nh;
-            uint8_t *hbits = hs.get<uint8_t>(nheavy);
-            uint32_t *nstretch = hs.get<uint32_t>(nheavy), *nseg = hs.get<uint32_t>(nheavy);
-            uint64_t *nhist = hs.get<uint64_t>(nheavy);
-            uint64_t *blkbase = hs.get<uint64_t>((uint64_t)nheavy + 1), *vbase = hs.get<uint64_t>((uint64_t)nheavy + 1),
-                     *hbase = hs.get<uint64_t>((uint64_t)nheavy + 1);
-            split_params_kernel<<<grid_for(nheavy, 256), 256, 0, s>>>(heavy_rows, nheavy, io.row_off, colbits, hbits, nstretch,
-                                                                      nseg, nhist);
-            device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nstretch}, nheavy, blkbase, hscan_tmp, s);
-            device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nseg}, nheavy, vbase, hscan_tmp, s);
-            device_exclusive_scan<LoadU64, uint64_t>(LoadU64{nhist}, nheavy, hbase, hscan_tmp, s);
-            const uint64_t nblocks = d2h(blkbase + nheavy, s), nvirt = d2h(vbase + nheavy, s), ncell = d2h(hbase + nheavy, s);
-            if (ncell >= 0xffffffffull || nblocks >= 0x7fffffffull) throw Error(OSP_ERR_CAPACITY, "split histogram too large");
-            uint32_t *ghist = hs.get<uint32_t>(ncell + 1);
-            uint32_t *ghist_tmp = hs.get<uint32_t>(scan_scratch_entries(ncell + 1));
-            split_count_kernel<<<(unsigned)nblocks, kSplitThreads, 0, s>>>(heavy_rows, nheavy, blkbase, hbase, hbits, nstretch,
-                                                                         io.row_off, base, colbits, (const char *)io.stage,
-                                                                         (uint32_t)sizeof(Part<T>), ghist);
-            device_exclusive_scan<LoadU32, uint32_t>(LoadU32{ghist}, ncell, ghist, ghist_tmp, s);
-            Part<T> *qstage = hs.get<Part<T>>(nh);
-            split_scatter_kernel<T><<<(unsigned)nblocks, kSplitThreads, 0, s>>>(heavy_rows, nheavy, blkbase, hbase, hbits,
-                                                                              nstretch, io.row_off, base, colbits, io.stage,
-                                                                              ghist, qstage);
-            uint64_t *vrow_off = hs.get<uint64_t>(nvirt + 1);
-            split_vrows_kernel<<<grid_for(nvirt + 1, 256), 256, 0, s>>>(nheavy, vbase, hbase, nstretch, ghist, nvirt, nh, vrow_off);
-            // merge the segments into a temporary CSR-like output
-            uint32_t *tcol = hs.get<uint32_t>(nh);
-            T *tval = hs.get<T>(nh);
-            int64_t *vptr = (int64_t *)hs.get<uint64_t>(nvirt + 1);
-            uint64_t *lvl_out = hs.get<uint64_t>(2);
-            OSP_HIP(hipMemsetAsync(lvl_out, 0, 2 * sizeof(uint64_t), s));
-            MergeIO<T> sub{qstage, vrow_off, 0, nvirt, 0, vptr, tcol, tval, lvl_out, lvl_out + 1};
-            merge_rows<T>(ctx, res, tm, sub, colbits, false);
-            split_rows_done_kernel<<<grid_for(nheavy, 256), 256, 0, s>>>(heavy_rows, nheavy, vbase, vptr, heavy_nnz, heavy_src);
-            hcopy_stage = nullptr;
-            hcopy_col = tcol;
-            hcopy_val = tval;
-        } else {
-            // ---- segments that are still too long: global stable sort on (rank, col), run sums in place ----
-            res->info.sorted_segments += nheavy;
-            res->info.sorted_partials += nh;
-            uint64_t *keys[2] = {hs.get<uint64_t>(nh), hs.get<uint64_t>(nh)};
-            uint32_t *poss[2] = {hs.get<uint32_t>(nh), hs.get<uint32_t>(nh)};
-            uint32_t *hist = hs.get<uint32_t>(sort_hist_entries(nh));
-            uint32_t *hist_tmp = hs.get<uint32_t>(scan_scratch_entries(sort_hist_entries(nh)));
-            heavy_fill_kernel<<<grid_for(nh, 256), 256, 0, s>>>(heavy_rows, hoff, nheavy, io.row_off, base, colbits,
-                                                                (const char *)io.stage, (uint32_t)sizeof(Part<T>), nh, keys[0], poss[0]);
-            const int nbits = colbits + bits_for(nheavy);
-            const int cur = device_radix_sort_pairs<uint64_t>(keys, poss, nh, nbits, hist, hist_tmp, s);
-            T *sorted_val = hs.get<T>(nh);
-            heavy_gather_kernel<T><<<grid_for(nh, 256), 256, 0, s>>>(poss[cur], io.stage, nh, sorted_val);
-            uint64_t *headscan = hs.get<uint64_t>(nh + 1);
-            uint64_t *headscan_tmp = hs.get<uint64_t>(scan_scratch_entries(nh));
-            device_exclusive_scan<HeavyHeadFlag, uint64_t>(HeavyHeadFlag{keys[cur]}, nh, headscan, headscan_tmp, s);
-            heavy_reduce_kernel<T><<<grid_for(nh, 256), 256, 0, s>>>(keys[cur], sorted_val, headscan, nh, heavy_rows, hoff,
-                                                                     nheavy, io.row_off, base, colbits, io.stage);
-            heavy_rows_kernel<<<grid_for(nheavy, 256), 256, 0, s>>>(heavy_rows, hoff, nheavy, headscan, heavy_nnz);
-            heavy_src_inplace_kernel<<<grid_for(nheavy, 256), 256, 0, s>>>(heavy_rows, nheavy, io.row_off, base, heavy_src);
+            fprintf(stderr, "[osp]   panel rows [%llu,%llu): %u tiles, %u long rows with %llu partial products -> %llu segments\n",
+                    (unsigned long long)r0, (unsigned long long)r1, p0.ntiles, nlong, (unsigned long long)nh, (unsigned long long)nvirt);
+        uint32_t *ghist = sc.get<uint32_t>(ncell + 1);
+        uint32_t *ghist_tmp = sc.get<uint32_t>(scan_scratch_entries(ncell + 1));
+        split_count_kernel<<<(unsigned)nblocks, kSplitThreads, 0, s>>>(p0.long_rows, nlong, blkbase, hbase, hbits, nstretch, io.row_off,
+                                                                     base, colbits, (const char *)io.stage, (uint32_t)sizeof(Part<T>), ghist);
+        device_exclusive_scan<LoadU32, uint32_t>(LoadU32{ghist}, ncell, ghist, ghist_tmp, s);
+        qstage = sc.get<Part<T>>(nh);
+        split_scatter_kernel<T><<<(unsigned)nblocks, kSplitThreads, 0, s>>>(p0.long_rows, nlong, blkbase, hbase, hbits, nstretch,
+                                                                          io.row_off, base, colbits, io.stage, ghist, qstage);
+        uint64_t *vrow_off = sc.get<uint64_t>(nvirt + 1);
+        uint8_t *vfirst = sc.get<uint8_t>(nvirt + 1);
+        split_vrows_kernel<<<grid_for(nvirt + 1, 256), 256, 0, s>>>(nlong, vbase, hbase, nstretch, ghist, nvirt, nh, vrow_off, vfirst);
+        // ---- tiles over the segments; a tile never spans two long rows ----
+        p1 = plan_tiles(ctx, sc, vrow_off, 0, nvirt, 0, kCap, max_rows, vfirst);
+        vptr = (int64_t *)sc.get<uint64_t>(nvirt + 1);
+        if (p1.nlong) {
+            // segments that are still too long (one column hit by thousands of products): global stable sort on
+            // (segment, col), run sums in place in the second buffer
+            const uint32_t nseg_long = p1.nlong;
+            res->info.sorted_segments += nseg_long;
+            uint64_t *soff = sc.get<uint64_t>((uint64_t)nseg_long + 1);
+            device_exclusive_scan<HeavyLen, uint64_t>(HeavyLen{p1.long_rows, vrow_off}, nseg_long, soff, hscan_tmp, s);
+            const uint64_t ns = d2h(soff + nseg_long, s);
+            res->info.sorted_partials += ns;
+            seg_src = sc.get<uint64_t>(nseg_long);
+            seg_nnz = sc.get<uint32_t>(nvirt + 1);
+            uint64_t *keys[2] = {sc.get<uint64_t>(ns), sc.get<uint64_t>(ns)};
+            uint32_t *poss[2] = {sc.get<uint32_t>(ns), sc.get<uint32_t>(ns)};
+            uint32_t *hist = sc.get<uint32_t>(sort_hist_entries(ns));
+            uint32_t *hist_tmp = sc.get<uint32_t>(scan_scratch_entries(sort_hist_entries(ns)));
+            heavy_fill_kernel<<<grid_for(ns, 256), 256, 0, s>>>(p1.long_rows, soff, nseg_long, vrow_off, 0, colbits, (const char *)qstage,
+                                                                (uint32_t)sizeof(Part<T>), ns, keys[0], poss[0]);
+            const int cur = device_radix_sort_pairs<uint64_t>(keys, poss, ns, colbits + bits_for(nseg_long), hist, hist_tmp, s);
+            T *sorted_val = sc.get<T>(ns);
+            heavy_gather_kernel<T><<<grid_for(ns, 256), 256, 0, s>>>(poss[cur], qstage, ns, sorted_val);
+            uint64_t *headscan = sc.get<uint64_t>(ns + 1);
+            uint64_t *headscan_tmp = sc.get<uint64_t>(scan_scratch_entries(ns));
+            device_exclusive_scan<HeavyHeadFlag, uint64_t>(HeavyHeadFlag{keys[cur]}, ns, headscan, headscan_tmp, s);
+            heavy_reduce_kernel<T><<<grid_for(ns, 256), 256, 0, s>>>(keys[cur], sorted_val, headscan, ns, p1.long_rows, soff, nseg_long,
+                                                                     vrow_off, 0, colbits, qstage);
+            heavy_rows_kernel<<<grid_for(nseg_long, 256), 256, 0, s>>>(p1.long_rows, soff, nseg_long, headscan, seg_nnz);
+            heavy_src_inplace_kernel<<<grid_for(nseg_long, 256), 256, 0, s>>>(p1.long_rows, nseg_long, vrow_off, 0, seg_src);
         }
+        lv.stage[1] = qstage; lv.row_off[1] = vrow_off; lv.base[1] = 0; lv.c_rowptr[1] = vptr; lv.heavy_nnz[1] = seg_nnz;
+        // ---- one chain: every long row's placeholder is replaced by the tiles of its segments ----
+        uint32_t *j0 = sc.get<uint32_t>(nlong), *tb = sc.get<uint32_t>((uint64_t)nlong + 1), *extra = sc.get<uint32_t>((uint64_t)nlong + 1);
+        chain_rows_kernel<<<grid_for(nlong + 1, 256), 256, 0, s>>>(p0.long_rows, nlong, p0.tile_rows, p0.ntiles, vbase, p1.tile_rows,
+                                                                  p1.ntiles, j0, tb, extra);
+        device_exclusive_scan<LoadU32, uint32_t>(LoadU32{extra}, nlong, extra, (uint32_t *)hscan_tmp, s);
+        ntot = p0.ntiles + d2h(extra + nlong, s);
+        desc = (TileDesc *)sc.get<uint64_t>((uint64_t)ntot * 3);
+        tile_desc_kernel<(int)kCap><<<grid_for(p0.ntiles, 256), 256, 0, s>>>(p0.tile_rows, p0.ntiles, r1, io.row_off, base, 0u, j0, extra,
+                                                                           nlong, tb, desc);
+        tile_desc_kernel<(int)kCap><<<grid_for(p1.ntiles, 256), 256, 0, s>>>(p1.tile_rows, p1.ntiles, nvirt, vrow_off, 0, 1u, j0, extra,
+                                                                           nlong, tb, desc);
+    } else {
+        desc = (TileDesc *)sc.get<uint64_t>((uint64_t)ntot * 3);
+        tile_desc_kernel<(int)kCap><<<grid_for(p0.ntiles, 256), 256, 0, s>>>(p0.tile_rows, p0.ntiles, r1, io.row_off, base, 0u, nullptr,
+                                                                           nullptr, 0u, nullptr, desc);
     }
-    if (ntiles) {
-        TileDesc *desc = (TileDesc *)sc.get<uint64_t>((uint64_t)ntiles * 3);
-        tile_desc_kernel<(int)kCap><<<grid_for(ntiles, 256), 256, 0, s>>>(tile_rows, ntiles, r1, io.row_off, base, desc);
-        uint64_t *tile_status = sc.get<uint64_t>(ntiles);
-        OSP_HIP(hipMemsetAsync(tile_status, 0, (uint64_t)ntiles * sizeof(uint64_t), s));
-        OSP_HIP(hipMemsetAsync(ticket, 0, sizeof(uint32_t), s));
-        tm.begin(PH_MERGE_K);
-        if (kMergeByRuns)
-            throw Error(OSP_ERR_ARG, "merge-by-runs build is only wired for bench_merge");
-        else
-            merge_tiles_kernel<T, kMergeThreads><<<std::min<uint32_t>(ntiles, ctx->merge_grid), kMergeThreads, 0, s>>>(
-                desc, ntiles, r1, io.row_off, base, colbits, io.stage, heavy_nnz, tile_status, ticket, io.out_in,
-                io.c_rowptr, io.c_col, io.c_val, io.out_out);
-        tm.end(PH_MERGE_K);
-        res->info.merge_launches++;
-    }
-    if (nheavy)
-        heavy_copy_kernel<T><<<nheavy * 8u, 256, 0, s>>>(heavy_rows, nheavy, heavy_src, heavy_nnz, io.c_rowptr, hcopy_stage,
-                                                         hcopy_col, hcopy_val, io.c_col, io.c_val);
+    uint64_t *tile_status = sc.get<uint64_t>(ntot);
+    uint32_t *ticket = sc.get<uint32_t>(1);
+    OSP_HIP(hipMemsetAsync(tile_status, 0, (uint64_t)ntot * sizeof(uint64_t), s));
+    OSP_HIP(hipMemsetAsync(ticket, 0, sizeof(uint32_t), s));
+    tm.begin(PH_MERGE_K);
+    merge_tiles_kernel<T, kMergeThreads><<<std::min<uint32_t>(ntot, ctx->merge_grid), kMergeThreads, 0, s>>>(
+        desc, ntot, lv, colbits, tile_status, ticket, io.out_in, io.c_col, io.c_val, io.out_out);
+    tm.end(PH_MERGE_K);
+    res->info.merge_launches++;
+    if (p1.nlong)
+        heavy_copy_kernel<T><<<p1.nlong * 8u, 256, 0, s>>>(p1.long_rows, p1.nlong, seg_src, seg_nnz, vptr, qstage, nullptr, nullptr,
+                                                           io.c_col, io.c_val);
+    chain_finish_kernel<<<grid_for(std::max<uint32_t>(p0.nlong, 1), 256), 256, 0, s>>>(p0.long_rows, p0.nlong, vbase, vptr, io.out_out, r1,
+                                                                                       io.c_rowptr);
     OSP_HIP(hipGetLastError());  // a rejected launch must not pass silently
 }
 
@@ -407,7 +431,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         // ---- merge ----
         tm.begin(PH_MERGE);
         MergeIO<T> io{stage, d_row_off, r0, r1, base, res->rowptr, c_col, c_val, out_nnz + p, out_nnz + p + 1};
-        merge_rows<T>(ctx, res, tm, io, colbits, true);
+        merge_panel<T>(ctx, res, tm, io, colbits);
         tm.end(PH_MERGE);
     }
     const uint64_t nnz_total = d2h(out_nnz + npanels, s);

@@ -239,9 +239,11 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
 struct CoarseStartFlag {
     const uint64_t *row_off;
     uint64_t r0, base, slot;
+    const uint8_t *force;  // optional: rows that must start a tile (first segment of a split long row)
     __device__ uint32_t operator()(uint64_t t) const {
         if (t == 0) return 1;
         const uint64_t r = r0 + t;
+        if (force && force[t]) return 1;
         return ((row_off[r] - base) / slot != (row_off[r - 1] - base) / slot || (t & 0xffffu) == 0) ? 1u : 0u;
     }
 };
@@ -370,14 +372,29 @@ __device__ __forceinline__ uint64_t lookback_prefix(uint64_t *status, uint32_t t
     return excl;
 }
 
-// One merge tile: rows [ra, ra+nr) whose partial products are staging[s, s+n).
+// One merge tile: rows [ra, ra+nr) of level `lvl` whose partial products are stage[lvl][s, s+n).
+// Level 0 = output rows in the staging buffer; level 1 = column-range segments of the split long rows
+// in the second buffer.  All tiles of a panel form ONE chain in output order: a long row's placeholder
+// in the level-0 list is replaced by the tiles of its segments.
 struct TileDesc {
     uint64_t s;
-    uint32_t ra, nr, n, pad;
+    uint32_t ra, nr, n, lvl;
 };
+// Everything merge_tiles_kernel needs per level.
+template <class T>
+struct MergeLevels {
+    const Part<T> *stage[2];
+    const uint64_t *row_off[2];
+    uint64_t base[2];
+    int64_t *c_rowptr[2];          // [0] the final rowptr, [1] offsets of the segments (same output space)
+    const uint32_t *heavy_nnz[2];  // entry counts of rows reduced outside the tile kernel (global-sort path)
+};
+// chain position of the level-`lvl` tile list; for level 0: j0 = sorted placeholder indices of the long
+// rows, extra = exclusive scan of (segment tiles of that long row - 1)
 template <int CAP>
 __global__ void tile_desc_kernel(const uint32_t *tile_rows, uint32_t ntiles, uint64_t r_end, const uint64_t *row_off,
-                                 uint64_t base, TileDesc *desc) {
+                                 uint64_t base, uint32_t lvl, const uint32_t *j0, const uint32_t *extra, uint32_t nlong,
+                                 const uint32_t *tb, TileDesc *desc) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
     const uint64_t ra = tile_rows[t], rb = (t + 1 < ntiles) ? (uint64_t)tile_rows[t + 1] : r_end;
@@ -386,8 +403,39 @@ __global__ void tile_desc_kernel(const uint32_t *tile_rows, uint32_t ntiles, uin
     d.ra = (uint32_t)ra;
     d.nr = (uint32_t)(rb - ra);
     d.n = (uint32_t)min(row_off[rb] - base - d.s, (uint64_t)CAP + 1);  // CAP+1 = "a single long row"
-    d.pad = 0;
-    desc[t] = d;
+    d.lvl = lvl;
+    uint32_t pos = t;
+    if (nlong) {
+        if (lvl == 0) {
+            if (d.n > (uint32_t)CAP) return;  // placeholder of a split long row: its segment tiles stand here
+            const uint32_t h = (uint32_t)lower_bound_dev(j0, 0, (uint64_t)nlong, t);  // long rows before tile t
+            pos = t + extra[h];
+        } else {
+            const uint32_t h = (uint32_t)(upper_bound_dev(tb, 0, (uint64_t)nlong + 1, t) - 1);  // owner long row
+            pos = j0[h] + extra[h] + (t - tb[h]);
+        }
+    }
+    desc[pos] = d;
+}
+// per split long row h: placeholder index in the level-0 tile list, first level-1 tile, tile count - 1
+__global__ void chain_rows_kernel(const uint32_t *heavy_rows, uint32_t nlong, const uint32_t *tile_rows0, uint32_t ntiles0,
+                                  const uint64_t *vbase, const uint32_t *tile_rows1, uint32_t ntiles1, uint32_t *j0,
+                                  uint32_t *tb, uint32_t *cntm1) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h > nlong) return;
+    if (h == nlong) { tb[h] = ntiles1; return; }
+    j0[h] = (uint32_t)lower_bound_dev(tile_rows0, 0, (uint64_t)ntiles0, heavy_rows[h]);
+    const uint32_t b = (uint32_t)lower_bound_dev(tile_rows1, 0, (uint64_t)ntiles1, vbase[h]);
+    const uint32_t e = (uint32_t)lower_bound_dev(tile_rows1, 0, (uint64_t)ntiles1, vbase[h + 1]);
+    tb[h] = b;
+    cntm1[h] = e - b - 1;
+}
+// after the merge: rowptr of the split long rows (= offset of their first segment) and of the panel end
+__global__ void chain_finish_kernel(const uint32_t *heavy_rows, uint32_t nlong, const uint64_t *vbase, const int64_t *vptr,
+                                    const uint64_t *out_end, uint64_t r_end, int64_t *c_rowptr) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < nlong) c_rowptr[heavy_rows[h]] = vptr[vbase[h]];
+    if (h == 0) c_rowptr[r_end] = (int64_t)*out_end;
 }
 
 // ABL: ablation switches for tools/bench_merge.hip only (1 = no sort, 2 = no look-back, 4 = no ticket);
@@ -399,11 +447,9 @@ __global__ void tile_desc_kernel(const uint32_t *tile_rows, uint32_t ntiles, uin
 // round trip instead of a chain of five.
 template <class T, int NT, int ABL = 0>
 __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two workgroups per CU
-    const TileDesc *__restrict__ desc, uint32_t ntiles, uint64_t r_end,
-    const uint64_t *__restrict__ row_off, uint64_t base, int colbits, const Part<T> *__restrict__ stage,
-    const uint32_t *__restrict__ heavy_nnz, uint64_t *tile_status,
-    uint32_t *ticket, const uint64_t *__restrict__ out_base_p, int64_t *__restrict__ c_rowptr,
-    uint32_t *__restrict__ c_col, T *__restrict__ c_val, uint64_t *__restrict__ out_end_p) {
+    const TileDesc *__restrict__ desc, uint32_t ntiles, const MergeLevels<T> lvl, int colbits, uint64_t *tile_status,
+    uint32_t *ticket, const uint64_t *__restrict__ out_base_p, uint32_t *__restrict__ c_col, T *__restrict__ c_val,
+    uint64_t *__restrict__ out_end_p) {
     __shared__ MergeSmem<T, NT> sm;
     __shared__ TileDesc s_dnext;
     __shared__ uint32_t s_tnext;
@@ -433,7 +479,8 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
     auto request = [&](const TileDesc &dd, bool ok) {
         const bool fetch = ok && dd.n <= (uint32_t)kTileCap;
         ro = 0;
-        if (fetch && tid <= dd.nr) ro = row_off[dd.ra + tid];
+        const Part<T> *__restrict__ stage = lvl.stage[dd.lvl];
+        if (fetch && tid <= dd.nr) ro = lvl.row_off[dd.lvl][dd.ra + tid];
 #pragma unroll
         for (int q = 0; q < LPT; q++) {
             const uint32_t i = tid + q * NT;
@@ -444,8 +491,9 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
     request(d, t < ntiles);
     __syncthreads();  // everybody holds t / d before the slots are refilled
     while (t < ntiles) {
-        const uint64_t ra = d.ra, s = d.s;
+        const uint64_t ra = d.ra, s = d.s, base = lvl.base[d.lvl];
         const uint32_t nr = d.nr, n = d.n;
+        int64_t *__restrict__ c_rowptr = lvl.c_rowptr[d.lvl];
         const bool long_row = n > (uint32_t)kTileCap;
         // The next tile's ticket is taken only AFTER this tile's look-back has returned: a workgroup that
         // is still waiting for its predecessors must not sit on a ticket, or every later tile queues up
@@ -455,12 +503,12 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
             // a single long row, already reduced by the split / global-sort path: it only takes part in the
             // offset chain; heavy_copy_kernel moves its entries once c_rowptr is known
             if (w == 0) {
-                const uint64_t total = heavy_nnz[ra];
+                const uint64_t total = lvl.heavy_nnz[d.lvl][ra];
                 const uint64_t excl = (ABL & 2) ? (uint64_t)t * kTileCap : lookback_prefix(tile_status, t, total);
                 if (lane == 0) {
                     tn_reg = (ABL & 4) ? t + gridDim.x : atomicAdd(ticket, 1u);
                     c_rowptr[ra] = (int64_t)(out_base + excl);
-                    if (t + 1 == ntiles) { c_rowptr[r_end] = (int64_t)(out_base + excl + total); *out_end_p = out_base + excl + total; }
+                    if (t + 1 == ntiles) *out_end_p = out_base + excl + total;
                     s_tnext = tn_reg;
                     if (tn_reg < ntiles) s_dnext = desc[tn_reg];
                 }
@@ -614,7 +662,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
         for (uint32_t o = tid; o < total; o += NT) { c_col[obase + o] = sm.key[cur ^ 1][o]; c_val[obase + o] = sm.val[o]; }
         // rows keep their index span through the sort (row is the major key)
         if (tid < nr) c_rowptr[ra + tid] = (int64_t)(obase + sm.rank[sm.rowo[tid]]);
-        if (t + 1 == ntiles && tid == 0) { c_rowptr[r_end] = (int64_t)(obase + total); *out_end_p = obase + total; }
+        if (t + 1 == ntiles && tid == 0) *out_end_p = obase + total;
         t = tn;
         d = dn;
         __syncthreads();  // LDS is reused by the next tile

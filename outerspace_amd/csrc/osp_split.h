@@ -159,13 +159,15 @@ __global__ __launch_bounds__(kSplitThreads) void split_scatter_kernel(
 
 // segment v of the split = "virtual row": its offset in the second buffer
 __global__ void split_vrows_kernel(uint32_t nheavy, const uint64_t *vbase, const uint64_t *hbase, const uint32_t *nstretch,
-                                   const uint32_t *goffs, uint64_t nvirt, uint64_t nh_total, uint64_t *vrow_off) {
+                                   const uint32_t *goffs, uint64_t nvirt, uint64_t nh_total, uint64_t *vrow_off,
+                                   uint8_t *vfirst) {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v > nvirt) return;
-    if (v == nvirt) { vrow_off[v] = nh_total; return; }
+    if (v == nvirt) { vrow_off[v] = nh_total; vfirst[v] = 1; return; }
     const uint32_t h = (uint32_t)(upper_bound_dev(vbase, 0, (uint64_t)nheavy + 1, v) - 1);
     const uint64_t d = v - vbase[h];
     vrow_off[v] = goffs[hbase[h] + d * nstretch[h]];
+    vfirst[v] = d == 0;  // first segment of a long row: a tile must start here
 }
 // merged long row h: its entry count and where it sits in the temporary output
 __global__ void split_rows_done_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *vbase, const int64_t *vptr,

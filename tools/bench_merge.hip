@@ -78,8 +78,10 @@ float run(uint32_t *tile_rows, uint32_t ntiles, uint64_t M, uint64_t *row_off, u
     CK(hipMemsetAsync(ticket, 0, 4, 0));
     CK(hipMemsetAsync(outn, 0, 16, 0));
     CK(hipEventRecord(a, 0));
-    merge_tiles_kernel<double, NT, ABL><<<ntiles < g_grid ? ntiles : g_grid, NT, 0, 0>>>(g_desc, ntiles, M, row_off, 0, 22, g_stage, heavy, status,
-                                                              ticket, outn, rowptr, ccol, cval, outn + 1);
+    MergeLevels<double> lv{};
+    lv.stage[0] = g_stage; lv.row_off[0] = row_off; lv.base[0] = 0; lv.c_rowptr[0] = rowptr; lv.heavy_nnz[0] = heavy;
+    merge_tiles_kernel<double, NT, ABL><<<ntiles < g_grid ? ntiles : g_grid, NT, 0, 0>>>(g_desc, ntiles, lv, 22, status, ticket, outn,
+                                                                                         ccol, cval, outn + 1);
     CK(hipEventRecord(b, 0));
     CK(hipEventSynchronize(b));
     float ms;
@@ -110,7 +112,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&g_stage, P * sizeof(Part<double>)));
     pack_kernel<<<(unsigned)((P + 255) / 256), 256>>>(pcol, pval, P, g_stage);
     CK(hipMalloc(&g_desc, (uint64_t)ntiles * sizeof(TileDesc)));
-    tile_desc_kernel<3072><<<(ntiles + 255) / 256, 256>>>(tile_rows, ntiles, M, row_off, 0, g_desc);
+    tile_desc_kernel<3072><<<(ntiles + 255) / 256, 256>>>(tile_rows, ntiles, M, row_off, 0, 0u, nullptr, nullptr, 0u, nullptr, g_desc);
     if (getenv("GRID")) g_grid = atoi(getenv("GRID"));
     CK(hipDeviceSynchronize());
     printf("P=%llu partials, %u tiles of %u rows x %u (%u per tile), algorithmic bytes %.2f GB\n", (unsigned long long)P, ntiles, rpt,
