@@ -306,6 +306,7 @@ struct MergeSmem {
     uint32_t rowo[kTileMaxRows + 1];
     uint32_t scratch[NT / kWave + 1];
     uint32_t tile;
+    uint32_t hcount;  // distinct (row, col) keys of the tile, counted by hashing before the sort
     uint64_t excl;
 };
 
@@ -331,11 +332,14 @@ __device__ __forceinline__ void wave_match_digit(unsigned digit, bool valid, uns
 // extra polling traffic costs more than the walk saves -- so kLookWin = 1; what matters is that tiles
 // are ticketed in the order they will finish, see merge_tiles_kernel.)
 constexpr int kLookWin = 1;
+// Make tile t's entry count visible to its successors (one lane).
+__device__ __forceinline__ void lookback_publish(uint64_t *status, uint32_t t, uint64_t total) {
+    __hip_atomic_store(&status[t], (t == 0 ? kStatusPrefix : kStatusAgg) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool PUBLISH = true>
 __device__ __forceinline__ uint64_t lookback_prefix(uint64_t *status, uint32_t t, uint64_t total) {
     const unsigned lane = lane_id();
-    if (lane == 0)
-        __hip_atomic_store(&status[t], (t == 0 ? kStatusPrefix : kStatusAgg) | total, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+    if (PUBLISH && lane == 0) lookback_publish(status, t, total);
     uint64_t excl = 0;
     int64_t b = (int64_t)t - 1;
     while (b >= 0) {
@@ -520,23 +524,50 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
             __syncthreads();
             continue;
         }
+        int rowbits = 0;
+        while ((1u << rowbits) < nr) rowbits++;
+        const int nbits = (n && !(ABL & 1)) ? colbits + rowbits : 0;
+        // The tile's entry count (= distinct keys) is needed by every later tile's look-back.  Waiting for
+        // the sort to deliver it makes successors stall behind slower predecessors; a hash set over the keys
+        // gives the same number right after staging, ~10 us earlier.  The table lives in LDS that is idle until
+        // the first sort pass (key[1], pos[], rank[]: exactly 2.5 words per entry).
+        constexpr uint32_t HS = (uint32_t)kTileCap * 5u / 2u;
+        uint32_t *htab = &sm.key[1][0];
+        const bool early = nbits > 0 && colbits + rowbits < 32 && !(ABL & 2);
+        if (early) {
+            for (uint32_t i = tid; i < HS; i += NT) htab[i] = 0xffffffffu;
+            if (tid == 0) sm.hcount = 0;
+        }
         if (tid <= nr) sm.rowo[tid] = (uint32_t)(ro - base - s);
         __syncthreads();
-        // stage: key = (local row << colbits) | col, payload = staging position
+        // stage: key = (local row << colbits) | col; the payload (staging position) is implicit until pass 0
+        uint32_t fresh = 0;
 #pragma unroll
         for (int q = 0; q < LPT; q++) {
             const uint32_t i = tid + q * NT;
             if (i < n) {
                 uint32_t lo = 0, hi = nr;  // last r with rowo[r] <= i
                 while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sm.rowo[mid] <= i) lo = mid; else hi = mid; }
-                sm.key[0][i] = (colbits < 32 ? (lo << colbits) : 0u) | lc[q];
-                sm.pos[0][i] = (uint16_t)i;
+                const uint32_t k = (colbits < 32 ? (lo << colbits) : 0u) | lc[q];
+                sm.key[0][i] = k;
                 sm.val[i] = lv[q];
+                if (early) {
+                    uint32_t h = (uint32_t)(((uint64_t)(k * 2654435761u) * HS) >> 32);
+                    while (true) {
+                        const uint32_t old = atomicCAS(&htab[h], 0xffffffffu, k);
+                        if (old == 0xffffffffu) { fresh++; break; }
+                        if (old == k) break;
+                        h = (h + 1 == HS) ? 0u : h + 1;
+                    }
+                }
             }
         }
-        int rowbits = 0;
-        while ((1u << rowbits) < nr) rowbits++;
-        const int nbits = (n && !(ABL & 1)) ? colbits + rowbits : 0;
+        if (early) {
+            const uint32_t wsum = wave_reduce_sum(fresh);
+            if (lane == 0 && wsum) atomicAdd(&sm.hcount, wsum);
+            __syncthreads();
+            if (tid == 0) lookback_publish(tile_status, t, sm.hcount);
+        }
         // each wave ranks a contiguous span, so earlier waves = earlier positions (stable)
         const uint32_t per = (n + NW - 1) / NW;
         const uint32_t wbeg = min(w * per, n), wend = min(wbeg + per, n);
@@ -588,10 +619,14 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
                     const uint32_t k = kreg[it];
                     const uint32_t dst = (uint32_t)sm.cnt[w][(k >> shift) & dmask] + rreg[it];
                     sm.key[cur ^ 1][dst] = k;
-                    sm.pos[cur ^ 1][dst] = sm.pos[cur][i];
+                    sm.pos[cur ^ 1][dst] = pass == 0 ? (uint16_t)i : sm.pos[cur][i];
                 }
             }
             cur ^= 1;
+            __syncthreads();
+        }
+        if (npass == 0) {  // nothing was sorted (empty tile): the payload is still implicit
+            for (uint32_t i = tid; i < n; i += NT) sm.pos[0][i] = (uint16_t)i;
             __syncthreads();
         }
         // head flags + exclusive scan (blocked: thread owns IPT consecutive sorted entries)
@@ -611,7 +646,9 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
         // the tile's unique count is known: wave 0 runs the look-back and then requests the next ticket;
         // the ticket's round trip overlaps the run sums below
         if (w == 0) {
-            const uint64_t excl = (ABL & 2) ? (uint64_t)t * kTileCap : lookback_prefix(tile_status, t, total);
+            const uint64_t excl = (ABL & 2) ? (uint64_t)t * kTileCap
+                                 : early   ? lookback_prefix<false>(tile_status, t, total)  // count already published
+                                           : lookback_prefix<true>(tile_status, t, total);
             if (lane == 0) {
                 sm.excl = excl;
                 tn_reg = (ABL & 4) ? t + gridDim.x : atomicAdd(ticket, 1u);
