@@ -350,3 +350,29 @@ def test_f32_skewed_bit_exact(ctx, port):
     got, want = run_both(ctx, port, n, n, n, (rows, cols, vals), (rows, cols, vals), np.float32)
     assert got.info["heavy_rows"] > 0
     assert_same(got, want)
+
+
+def test_huge_column_space_and_many_empty_rows(ctx, port):
+    """N close to 2^32 (32 key bits for the column alone: one row per tile, no row bits) and an output with
+    almost only empty rows (tiles of 256 empty rows)."""
+    rng = np.random.default_rng(11)
+    M, K, N = 300, 64, 4_000_000_000
+    a = gen.random_coo(M, K, 0.05, seed=3)
+    b_rows = np.repeat(np.arange(K, dtype=np.uint32), 20)
+    b_cols = np.sort(rng.integers(0, N, (K, 20), dtype=np.int64), axis=1)
+    b_cols[:, 1] = b_cols[:, 0] + 1           # adjacent columns
+    b_cols[:, 19] = N - 1                      # every B row hits the last column -> duplicates to sum
+    b_cols = np.sort(b_cols, axis=1)
+    keep = np.ones(b_cols.shape, bool)
+    keep[:, 1:] = b_cols[:, 1:] != b_cols[:, :-1]
+    b = (b_rows[keep.reshape(-1)], b_cols.reshape(-1)[keep.reshape(-1)].astype(np.uint32), rng.uniform(0.5, 1.5, int(keep.sum())))
+    got, want = run_both(ctx, port, M, K, N, a, b, np.float64)
+    assert_same(got, want)
+    assert got.colidx.max() == N - 1
+    # 2 million output rows, 500 non-zeros of A
+    M2 = 2_000_000
+    a2 = (np.sort(rng.choice(M2, 500, replace=False)).astype(np.uint32), rng.integers(0, K, 500).astype(np.uint32),
+          rng.uniform(0.5, 1.5, 500))
+    b2 = gen.random_coo(K, 1000, 0.02, seed=5)
+    got, want = run_both(ctx, port, M2, K, 1000, a2, b2, np.float64)
+    assert_same(got, want)
