@@ -89,6 +89,10 @@ struct Context {
             }
         }
         live[p] = b;
+        // debugging aid: OSP_POISON=1 fills every buffer with 0xFF bytes, so that a read of memory nobody
+        // wrote fails the same way on every run instead of depending on what the pool hands back
+        static const bool poison = getenv("OSP_POISON") != nullptr;
+        if (poison) (void)hipMemsetAsync(p, 0xff, b, stream);
         return p;
     }
     void release(void *p) {
@@ -550,6 +554,10 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
 
     // ---- k shard ----
     const uint64_t k0 = cfg.k_begin, k1 = cfg.k_end ? cfg.k_end : K;
+    if (getenv("OSP_VERBOSE"))
+        fprintf(stderr, "[osp] spgemm M=%llu K=%llu N=%llu nnzA=%lld nnzB=%lld k=[%llu,%llu) %s operands\n", (unsigned long long)M,
+                (unsigned long long)K, (unsigned long long)N, (long long)nnz_a, (long long)nnz_b, (unsigned long long)k0,
+                (unsigned long long)k1, space == OSP_HOST ? "host" : "device");
     if (k0 > k1 || k1 > K) throw Error(OSP_ERR_ARG, "k range outside [0,K]");
     int64_t e0 = 0, e1 = nnz_a;
     if (k0 != 0 || k1 != K) {
@@ -649,6 +657,9 @@ static void merge_parts_impl(Context *ctx, Result *res, uint64_t M, uint64_t N, 
         nnz_in += nnz;
     }
     res->info.nnz_a = nnz_in;
+    if (getenv("OSP_VERBOSE"))
+        fprintf(stderr, "[osp] merge_csr_parts M=%llu N=%llu parts=%d entries=%llu %s operands\n", (unsigned long long)M,
+                (unsigned long long)N, nparts, (unsigned long long)nnz_in, space == OSP_HOST ? "host" : "device");
     const int64_t **d_rp = (const int64_t **)sc.get<void *>(nparts);
     const uint32_t **d_ci = (const uint32_t **)sc.get<void *>(nparts);
     const T **d_va = (const T **)sc.get<void *>(nparts);
