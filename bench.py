@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--partial-capacity", type=int, default=0)
     ap.add_argument("--cpu-baseline", type=int, default=1, help="time the CPU reference on a k-slab (rank 0, N=1)")
     ap.add_argument("--cpu-partials", type=float, default=2.5e8, help="partial products in the CPU sample slab")
+    ap.add_argument("--force-dist", type=int, default=0, help="run the k-sharded code path even with one rank (sanity check)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal only: exchange staged through host memory, ranks may share a GPU")
     return ap.parse_args()
@@ -138,8 +139,11 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
+        if world == 1 and "RANK" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -157,21 +161,26 @@ def main():
     ctx = S.Context(dev_index)
     ptrs = [t.data_ptr() for t in (*csc, *csr)]
 
-    if world == 1:
-        def step():
+    if not use_dist:
+        def step(checksum=False):
             res = ctx.spgemm_csc_csr_device(np_dtype, n, n, n, ptrs, validate=False,
                                             partial_capacity=args.partial_capacity)
             info = res.info
+            if checksum:
+                from outerspace_amd.distributed import _as_tensor
+                _, _, va = res.device_ptrs()
+                info["val_sum_global"] = float(_as_tensor(va, res.nnz, "<f8" if args.dtype == "f64" else "<f4", device, tdtype)
+                                               .sum(dtype=torch.float64))
             res.close()
             return info
     else:
         from outerspace_amd import distributed as D
         plan = D.plan_k_shards(csc[0], csr[0], world)
 
-        def step():
+        def step(checksum=False):
             return D.spgemm_k_sharded(ctx, np_dtype, n, n, n, csc, csr, plan, dist, rank, world,
                                       partial_capacity=args.partial_capacity,
-                                      stage_through_host=args.dist_backend == "gloo")
+                                      stage_through_host=args.dist_backend == "gloo", checksum=checksum)
 
     for _ in range(args.warmup):
         step()
@@ -189,7 +198,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     info = infos[-1]
-    nnz_c, P = info["nnz_c_global"] if world > 1 else info["nnz_c"], info["partials_global"] if world > 1 else info["partials"]
+    # untimed sanity check of the whole result: 1^T C 1 must equal (1^T A)(B 1)
+    chk = step(checksum=True)
+    colsum_a = torch.zeros(n, dtype=torch.float64, device=device).index_add_(
+        0, torch.repeat_interleave(torch.arange(n, device=device), csc[0][1:] - csc[0][:-1]), csc[2].double())
+    rowsum_b = torch.zeros(n, dtype=torch.float64, device=device).index_add_(
+        0, torch.repeat_interleave(torch.arange(n, device=device), csr[0][1:] - csr[0][:-1]), csr[2].double())
+    want_sum = float((colsum_a * rowsum_b).sum())
+    rel = abs(chk["val_sum_global"] - want_sum) / max(abs(want_sum), 1e-300)
+    if rel > (1e-9 if args.dtype == "f64" else 1e-4):
+        raise SystemExit(f"RESULT CHECK FAILED: sum(C) = {chk['val_sum_global']!r}, expected {want_sum!r} (rel {rel:.3e})")
+    nnz_c, P = info["nnz_c_global"] if use_dist else info["nnz_c"], info["partials_global"] if use_dist else info["partials"]
     ms_step = dt / args.steps * 1e3
 
     if rank == 0:
@@ -226,8 +245,9 @@ def main():
             "panels": info["panels"], "long_rows_split": info["heavy_rows"], "long_row_partials": info["heavy_partials"],
             "segments_global_sorted": info["sorted_segments"], "segment_partials_global_sorted": info["sorted_partials"],
             "roofline": roof,
+            "result_check": {"sum_C": chk["val_sum_global"], "expected_(1^T A)(B 1)": want_sum, "rel_err": rel},
         }
-        if world > 1:
+        if use_dist:
             out["phases_ms"].update({k: mean(k) for k in ("ms_exchange", "ms_final_merge") if k in info})
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(csc, csr, n, args.cpu_partials, np_dtype)

@@ -50,6 +50,42 @@ def plan_row_ranges(row_weight, world):
     return bounds
 
 
+# RCCL (ROCm 7.0.2 build shipped with torch 2.10) delivers only the first half of an all_to_all_single message
+# larger than 2^30 bytes (tools/repro_a2a.py: 1.07 GB intact, 1.2 GB and up truncated, also with one rank).
+# Large exchanges therefore go in rounds of at most this many bytes per (source, destination) pair.
+A2A_MAX_BYTES = 1 << 29
+
+
+def all_to_all_v(dst, src, recv_l, send_l, dist, world, group=None, max_bytes=None):
+    """dst/src: 1-D tensors; rank h receives src's slice h of every rank (split sizes in elements)."""
+    max_bytes = max_bytes or A2A_MAX_BYTES
+    ch = max(1, max_bytes // src.element_size())
+    biggest = torch.tensor([max(list(send_l) + list(recv_l) + [0])], dtype=torch.int64, device=src.device)
+    dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)
+    rounds = (int(biggest[0]) + ch - 1) // ch
+    if rounds <= 1:
+        dist.all_to_all_single(dst, src, list(recv_l), list(send_l), group=group)
+        return
+    soff = [0] * (world + 1)
+    roff = [0] * (world + 1)
+    for h in range(world):
+        soff[h + 1] = soff[h] + send_l[h]
+        roff[h + 1] = roff[h] + recv_l[h]
+    lists_ok = dist.get_backend(group) == "nccl"  # gloo has no list all_to_all: pack the round's pieces instead
+    for r in range(rounds):
+        ins = [src[soff[h] + min(r * ch, send_l[h]): soff[h] + min((r + 1) * ch, send_l[h])] for h in range(world)]
+        outs = [dst[roff[g] + min(r * ch, recv_l[g]): roff[g] + min((r + 1) * ch, recv_l[g])] for g in range(world)]
+        if lists_ok:
+            dist.all_to_all(outs, ins, group=group)  # views: no packing
+        else:
+            tmp = torch.empty(sum(o.numel() for o in outs), dtype=dst.dtype, device=dst.device)
+            dist.all_to_all_single(tmp, torch.cat(ins), [o.numel() for o in outs], [i.numel() for i in ins], group=group)
+            o0 = 0
+            for o in outs:
+                o.copy_(tmp[o0:o0 + o.numel()])
+                o0 += o.numel()
+
+
 def exchange_partial_csr(rowptr, colidx, vals, dist, world, group=None):
     """All-to-all-v of a partial CSR (all M rows) so that rank h ends up with every rank's rows of range h.
 
@@ -74,11 +110,11 @@ def exchange_partial_csr(rowptr, colidx, vals, dist, world, group=None):
     row_send = [rb[h + 1] - rb[h] for h in range(world)]
     # per-row counts of my range as computed by every rank
     cnt_recv = torch.empty(nr * world, dtype=torch.int32, device=rowptr.device)
-    dist.all_to_all_single(cnt_recv, rownnz, [nr] * world, row_send, group=group)
+    all_to_all_v(cnt_recv, rownnz, [nr] * world, row_send, dist, world, group)
     col_recv = torch.empty(sum(recv_l), dtype=colidx.dtype, device=colidx.device)
     val_recv = torch.empty(sum(recv_l), dtype=vals.dtype, device=vals.device)
-    dist.all_to_all_single(col_recv, colidx, recv_l, send_l, group=group)
-    dist.all_to_all_single(val_recv, vals, recv_l, send_l, group=group)
+    all_to_all_v(col_recv, colidx, recv_l, send_l, dist, world, group)
+    all_to_all_v(val_recv, vals, recv_l, send_l, dist, world, group)
     parts, o = [], 0
     for g in range(world):
         rp = torch.zeros(nr + 1, dtype=torch.int64, device=rowptr.device)
@@ -126,7 +162,7 @@ def _as_tensor(ptr, n, typestr, device, dtype):
 
 
 def spgemm_k_sharded(ctx, np_dtype, M, K, N, csc, csr, k_bounds, dist, rank, world, partial_capacity=0,
-                     stage_through_host=False):
+                     stage_through_host=False, checksum=False):
     """The GPU instantiation used by bench.py.  csc/csr: (ptr int64, idx int32, vals) CUDA tensors holding
     the FULL operands on every rank (each rank touches only its k slab).  Returns an info dict.
 
@@ -166,6 +202,12 @@ def spgemm_k_sharded(ctx, np_dtype, M, K, N, csc, csr, k_bounds, dist, rank, wor
     info.update(nnz_c_global=int(tot[0]), partials_global=int(tot[1]), nnz_c_final_local=fin["nnz_c"],
                 ms_local=out["seconds"][0] * 1e3, ms_exchange=out["seconds"][1] * 1e3,
                 ms_final_merge=out["seconds"][2] * 1e3, final_merge_partials=fin["partials"])
+    if checksum:  # sum of all values of C (all ranks), for the 1^T C 1 = (1^T A)(B 1) sanity check
+        _, _, va = keep["final"].device_ptrs()
+        vs = _as_tensor(va, fin["nnz_c"], vt, device, tdt).sum(dtype=torch.float64).reshape(1)
+        vs = vs.cpu() if stage_through_host else vs
+        dist.all_reduce(vs)
+        info["val_sum_global"] = float(vs[0])
     keep["local"].close()
     keep["final"].close()
     return info

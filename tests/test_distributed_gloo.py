@@ -44,6 +44,7 @@ def _worker(rank, world, port, preset, out_dir):
             acc.sort_indices()
             return acc.indptr.astype(np.int64), acc.indices.astype(np.uint32), acc.data
 
+        D.A2A_MAX_BYTES = 4096 if preset == "g500" else (1 << 29)  # g500 case: force the multi-round exchange
         out = D.k_sharded_product(local_product, merge_parts, bounds, dist, world)
         rb = out["row_bounds"]
         full = po.spgemm(n, n, n, acp, ari, av, brp, bci, bv)
