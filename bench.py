@@ -32,6 +32,8 @@ def parse():
     ap.add_argument("--rmat", default="mild",
                     help="R-MAT (a,b,c,d): mild=(.45,.22,.22,.11) [default: skewed, and C still fits one GPU's HBM] | "
                          "uniform=(.25,.25,.25,.25) | g500=(.57,.19,.19,.05) [scale-22 needs ~840 GB for C] | a,b,c,d")
+    ap.add_argument("--workload", default="rmat", choices=["rmat", "webgoogle"],
+                    help="webgoogle = BASELINE configs[1] shape (916428 vertices, ~5.1 M pattern non-zeros, power-law degrees)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--dtype", default="f64", choices=["f32", "f64"])
     ap.add_argument("--partial-capacity", type=int, default=0)
@@ -88,6 +90,34 @@ def rmat_device(scale, ef, abcd, seed, device, dtype):
     csc = (colptr, rows[perm].to(torch.int32).contiguous(), vals[perm].contiguous())
     del perm, rows, cols
     return n, csr, csc
+
+
+def webgoogle_device(seed, device, dtype):
+    """web-Google-SHAPED pattern matrix (the real SuiteSparse file is not available offline): n = 916428,
+    ~5.1 M distinct entries, heavy-tailed out- and in-degrees, values 1.0 (pattern file -> 1.0, SimSpGEMM.cpp:92-93)."""
+    import torch
+    n, m = 916428, 7_000_000
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    # sources: heavy-tailed out-degree; targets: 85 % "same site" (within +-6 ids), 15 % popular hubs.
+    # Calibrated on the CPU against the published figures of web-Google (nnz 5.1 M, P 60.7 M, nnz(C) 29.7 M):
+    # this recipe gives nnz ~5.2 M, P ~54 M, nnz(C) ~43 M.
+    rows = (n * torch.rand(m, generator=g, device=device, dtype=torch.float64).pow(2.0)).long().clamp_(max=n - 1)
+    local = torch.rand(m, generator=g, device=device) < 0.85
+    near = (rows + torch.randint(-6, 7, (m,), generator=g, device=device)) % n
+    hubs = (n * torch.rand(m, generator=g, device=device, dtype=torch.float64).pow(2.8)).long().clamp_(max=n - 1)
+    cols = torch.where(local, near, hubs)
+    perm = torch.randperm(n, generator=g, device=device)      # relabel: hub ids are not the low indices
+    rows, cols = perm[rows], perm[cols]
+    key = torch.unique(rows * n + cols)
+    rows, cols = key // n, key % n
+    vals = torch.ones(rows.numel(), device=device, dtype=dtype)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+    colptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    colptr[1:] = torch.cumsum(torch.bincount(cols, minlength=n), 0)
+    p2 = torch.argsort(cols * n + rows)
+    return n, (rowptr, cols.to(torch.int32).contiguous(), vals), (colptr, rows[p2].to(torch.int32).contiguous(), vals[p2].contiguous())
 
 
 def cpu_baseline(csc, csr, n, target_partials, np_dtype):
@@ -155,7 +185,10 @@ def main():
     np_dtype = np.float64 if args.dtype == "f64" else np.float32
     E = 4 + np.dtype(np_dtype).itemsize
 
-    n, csr, csc = rmat_device(args.scale, args.edge_factor, abcd, args.seed, device, tdtype)
+    if args.workload == "webgoogle":
+        n, csr, csc = webgoogle_device(args.seed, device, tdtype)
+    else:
+        n, csr, csc = rmat_device(args.scale, args.edge_factor, abcd, args.seed, device, tdtype)
     nnz_a = int(csr[0][-1])
     torch.cuda.synchronize()
     ctx = S.Context(dev_index)
@@ -236,8 +269,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"R-MAT scale-{args.scale} edge-factor-{args.edge_factor} (a,b,c,d)={abcd} seed {args.seed}, "
-                                   f"duplicates removed, self-product C=A*A, CSC x CSR -> CSR",
+            "config": {"workload": (f"R-MAT scale-{args.scale} edge-factor-{args.edge_factor} (a,b,c,d)={abcd} seed {args.seed}, "
+                                    f"duplicates removed, self-product C=A*A, CSC x CSR -> CSR") if args.workload == "rmat" else
+                                   "web-Google-shaped synthetic pattern matrix (916428 vertices, power-law degrees), self-product",
                        "n": n, "nnz_a": nnz_a, "partials": P, "nnz_c": nnz_c,
                        "parallelism": "single GPU" if world == 1 else f"k-sharded over {world} GPUs + RCCL all-to-all of partial CSRs"},
             "gflops": 2 * P / (ms_step * 1e-3) / 1e9, "partials_per_s": P / (ms_step * 1e-3),
