@@ -156,6 +156,16 @@ struct LoadU64 {
     __device__ uint64_t operator()(uint64_t i) const { return p[i]; }
 };
 
+// value of lane `src` (wave-uniform index) for every lane
+__device__ __forceinline__ uint32_t wave_bcast(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }
+__device__ __forceinline__ uint64_t wave_bcast(uint64_t v, uint32_t src) {
+    return ((uint64_t)wave_bcast((uint32_t)(v >> 32), src) << 32) | wave_bcast((uint32_t)v, src);
+}
+__device__ __forceinline__ float wave_bcast(float v, uint32_t src) { return __uint_as_float(wave_bcast(__float_as_uint(v), src)); }
+__device__ __forceinline__ double wave_bcast(double v, uint32_t src) {
+    return __longlong_as_double((long long)wave_bcast((uint64_t)__double_as_longlong(v), src));
+}
+
 // ---- multiply ----------------------------------------------------------------------------------
 // Reference: cscMulcsr, SimSpGEMM.cpp:265-281.  The panel's products are numbered k-major,
 // then by A entry j, then by B entry l; wave `wv` owns products [wv*kMulPerWave, ...).  For each
@@ -197,17 +207,26 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
             j1 = (b - 1) / nb; lb = b - j1 * nb;
         }
         if (nb > 32) {
-            for (uint32_t l0 = 0; l0 < nb; l0 += kWave) {
-                const uint32_t l = l0 + lane;
-                const bool in = l < nb;
-                uint32_t bc = 0; T bv = 0;
-                if (in) { bc = b_colidx[bs + l]; bv = b_vals[bs + l]; }
-                for (uint64_t j = j0; j <= j1; j++) {
-                    const uint64_t e = as + j;
-                    const T av = a_vals[e];
-                    const uint64_t off = chunk_off[e - (uint64_t)e0] - base;
-                    const bool ok = in && !(j == j0 && l < la) && !(j == j1 && l >= lb);
-                    if (ok) stage[off + l] = Part<T>{bc, av * bv};
+            // A entries in batches of 64: lane q fetches entry jb+q's value and chunk offset once, the inner loop
+            // reads them with v_readlane -- no dependent global load per chunk
+            for (uint64_t jb = j0; jb <= j1; jb += kWave) {
+                const uint64_t jm = jb + lane;
+                T av_l = 0;
+                uint64_t off_l = 0;
+                if (jm <= j1) { av_l = a_vals[as + jm]; off_l = chunk_off[as + jm - (uint64_t)e0] - base; }
+                const uint32_t cj = (uint32_t)min((uint64_t)kWave, j1 - jb + 1);
+                for (uint32_t l0 = 0; l0 < nb; l0 += kWave) {
+                    const uint32_t l = l0 + lane;
+                    const bool in = l < nb;
+                    uint32_t bc = 0; T bv = 0;
+                    if (in) { bc = b_colidx[bs + l]; bv = b_vals[bs + l]; }
+                    for (uint32_t q = 0; q < cj; q++) {
+                        const uint64_t j = jb + q;
+                        const T av = wave_bcast(av_l, q);
+                        const uint64_t off = wave_bcast(off_l, q);
+                        const bool ok = in && !(j == j0 && l < la) && !(j == j1 && l >= lb);
+                        if (ok) stage[off + l] = Part<T>{bc, av * bv};
+                    }
                 }
             }
         } else {
