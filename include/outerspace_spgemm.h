@@ -13,7 +13,7 @@
  *   mulflops_ref                            SimSpGEMM.cpp:884-891  osp_result_info.partials
  *   COOMatrix readcoo(istream&, NRow, NCol, sym)
  *                                           SimSpGEMM.cpp:55-100   osp_mtx_read
- *   CSRMatrix coo2csr<transpose>(coo, N)    SimSpGEMM.cpp:102-152  osp_coo_to_compressed_*
+ *   CSRMatrix coo2csr<transpose>(coo, N)    SimSpGEMM.cpp:102-152  osp_coo_to_compressed_* (host), osp_spgemm_coo (GPU)
  *   dupcheck -> throw(233)                  SimSpGEMM.cpp:43-53    OSP_ERR_DUPLICATE (= 233)
  *   assert(csc.pos.size()==csr.pos.size())  SimSpGEMM.cpp:267,882  OSP_ERR_DIM
  *   main(argv[1]=A.mtx, argv[2]=B.mtx)      SimSpGEMM.cpp:819-894  osp_spgemm_mtx / tools/osp_spgemm
@@ -83,6 +83,7 @@ typedef struct osp_result_info {
     uint64_t sorted_partials;
     float ms_symbolic, ms_multiply, ms_merge, ms_compact, ms_total;   /* phases (all launches in them) */
     float ms_multiply_kernel, ms_merge_kernel;  /* multiply_kernel / merge_tiles_kernel launches alone */
+    float ms_ingest;            /* osp_spgemm_coo / osp_spgemm_mtx: COO -> CSC/CSR on the device (included in ms_total) */
     uint32_t multiply_launches, merge_launches; /* number of those launches */
     int dtype;
 } osp_result_info_t;
@@ -111,6 +112,17 @@ int osp_spgemm_csc_csr(osp_context_t ctx, osp_dtype_t dtype, uint64_t M, uint64_
                        const int64_t *a_colptr, const uint32_t *a_rowidx, const void *a_vals,
                        const int64_t *b_rowptr, const uint32_t *b_colidx, const void *b_vals,
                        osp_memspace_t space, const osp_config_t *cfg, osp_result_t *result);
+
+/*
+ * Same product from COO operands in any order: the conversion the reference does on the host with two
+ * std::sorts -- csc = coo2csr<true>(A, K), csr = coo2csr(B, K), SimSpGEMM.cpp:878-879 / :102-152 -- runs on the
+ * GPU (stable radix sorts by (column,row) and (row,column)).  A duplicate coordinate in either operand returns
+ * OSP_ERR_DUPLICATE (233), an index outside its dimension OSP_ERR_RANGE.  `space` covers all six arrays.
+ */
+int osp_spgemm_coo(osp_context_t ctx, osp_dtype_t dtype, uint64_t M, uint64_t K, uint64_t N, uint64_t nnz_a,
+                   const uint32_t *a_rows, const uint32_t *a_cols, const void *a_vals, uint64_t nnz_b,
+                   const uint32_t *b_rows, const uint32_t *b_cols, const void *b_vals, osp_memspace_t space,
+                   const osp_config_t *cfg, osp_result_t *result);
 
 /*
  * Sum `nparts` CSR matrices of identical shape (MxN) into one CSR: the final step of the

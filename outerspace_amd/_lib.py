@@ -37,7 +37,7 @@ class ResultInfo(C.Structure):
                 ("sorted_segments", C.c_uint64), ("sorted_partials", C.c_uint64),
                 ("ms_symbolic", C.c_float), ("ms_multiply", C.c_float), ("ms_merge", C.c_float),
                 ("ms_compact", C.c_float), ("ms_total", C.c_float),
-                ("ms_multiply_kernel", C.c_float), ("ms_merge_kernel", C.c_float),
+                ("ms_multiply_kernel", C.c_float), ("ms_merge_kernel", C.c_float), ("ms_ingest", C.c_float),
                 ("multiply_launches", C.c_uint32), ("merge_launches", C.c_uint32), ("dtype", C.c_int)]
 
     def as_dict(self):
@@ -47,7 +47,7 @@ class ResultInfo(C.Structure):
 # every symbol include/outerspace_spgemm.h declares
 EXPORTS = [
     "osp_context_create", "osp_context_create_on_stream", "osp_context_destroy", "osp_context_trim",
-    "osp_config_default", "osp_last_error_string", "osp_status_string", "osp_spgemm_csc_csr",
+    "osp_config_default", "osp_last_error_string", "osp_status_string", "osp_spgemm_csc_csr", "osp_spgemm_coo",
     "osp_merge_csr_parts", "osp_result_info", "osp_result_copy_csr", "osp_result_device_ptrs",
     "osp_result_destroy", "osp_mtx_read", "osp_host_free", "osp_coo_to_compressed_f32",
     "osp_coo_to_compressed_f64", "osp_spgemm_mtx", "osp_result_write_mtx",
@@ -78,6 +78,7 @@ def lib():
     L.osp_config_default.restype = None
     L.osp_spgemm_csc_csr.argtypes = [vp, i32, u64, u64, u64, vp, vp, vp, vp, vp, vp, i32,
                                      C.POINTER(Config), C.POINTER(vp)]
+    L.osp_spgemm_coo.argtypes = [vp, i32, u64, u64, u64, u64, vp, vp, vp, u64, vp, vp, vp, i32, C.POINTER(Config), C.POINTER(vp)]
     L.osp_merge_csr_parts.argtypes = [vp, i32, u64, u64, i32, C.POINTER(vp), C.POINTER(vp),
                                       C.POINTER(vp), i32, C.POINTER(Config), C.POINTER(vp)]
     L.osp_result_info.argtypes = [vp, C.POINTER(ResultInfo)]

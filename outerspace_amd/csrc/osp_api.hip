@@ -633,6 +633,69 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     (void)hipEventDestroy(ev1);
 }
 
+// COO (device arrays, any order) -> compressed by `seg` with ascending `inner` indices; all outputs in `sc`.
+template <class T>
+static void coo_to_compressed_device(Context *ctx, Scratch &sc, uint64_t nseg, uint64_t ninner, uint64_t nnz, const uint32_t *seg,
+                                     const uint32_t *inner, const T *vals, const char *what, int64_t **ptr_out,
+                                     uint32_t **idx_out, T **val_out) {
+    hipStream_t s = ctx->stream;
+    int64_t *ptr = sc.get<int64_t>(nseg + 1);
+    uint32_t *idx = sc.get<uint32_t>(nnz);
+    T *ov = sc.get<T>(nnz);
+    *ptr_out = ptr; *idx_out = idx; *val_out = ov;
+    if (nnz == 0) {
+        OSP_HIP(hipMemsetAsync(ptr, 0, (nseg + 1) * sizeof(int64_t), s));
+        return;
+    }
+    Scratch ss(ctx);
+    uint32_t *ka = ss.get<uint32_t>(nnz), *pa = ss.get<uint32_t>(nnz), *kb = ss.get<uint32_t>(nnz), *pb = ss.get<uint32_t>(nnz);
+    uint32_t *k1 = ss.get<uint32_t>(nnz), *perm1 = ss.get<uint32_t>(nnz), *k2 = ss.get<uint32_t>(nnz);
+    uint32_t *seg_sorted = ss.get<uint32_t>(nnz), *perm2 = ss.get<uint32_t>(nnz);
+    uint32_t *hist = ss.get<uint32_t>(rs_hist_entries(nnz));
+    uint32_t *hist_tmp = ss.get<uint32_t>(scan_scratch_entries(rs_hist_entries(nnz)));
+    uint32_t *flags = ss.get<uint32_t>(1);
+    OSP_HIP(hipMemsetAsync(flags, 0, sizeof(uint32_t), s));
+    // stable LSD: by inner index first, then by segment
+    device_sort_rows<RsStoreEpilogue>(inner, nnz, std::max(1, bits_for(ninner)), ka, pa, kb, pb, hist, hist_tmp,
+                                      RsStoreEpilogue{k1, perm1}, s);
+    ingest_gather_u32_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(seg, perm1, nnz, k2);
+    device_sort_rows<RsStoreEpilogue>(k2, nnz, std::max(1, bits_for(nseg)), ka, pa, kb, pb, hist, hist_tmp,
+                                      RsStoreEpilogue{seg_sorted, perm2}, s, perm1);
+    ingest_finish_kernel<T><<<grid_for(nnz, 256), 256, 0, s>>>(seg_sorted, perm2, inner, vals, nnz, nseg, ninner, idx, ov, flags);
+    ingest_ptr_kernel<<<grid_for(nseg + 1, 256), 256, 0, s>>>(seg_sorted, nnz, nseg, ptr);
+    check_flags(d2h(flags, s), what);
+}
+
+template <class T>
+static void spgemm_coo_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint64_t N, uint64_t nnz_a, const uint32_t *a_rows,
+                            const uint32_t *a_cols, const T *a_vals, uint64_t nnz_b, const uint32_t *b_rows, const uint32_t *b_cols,
+                            const T *b_vals, osp_memspace_t space, const osp_config_t &cfg) {
+    hipStream_t s = ctx->stream;
+    Scratch sc(ctx);
+    hipEvent_t ev0, ev1;
+    OSP_HIP(hipEventCreate(&ev0));
+    OSP_HIP(hipEventCreate(&ev1));
+    OSP_HIP(hipEventRecord(ev0, s));
+    const uint32_t *ar = to_device(sc, a_rows, nnz_a, space, s), *ac = to_device(sc, a_cols, nnz_a, space, s);
+    const uint32_t *br = to_device(sc, b_rows, nnz_b, space, s), *bc = to_device(sc, b_cols, nnz_b, space, s);
+    const T *av = to_device(sc, a_vals, nnz_a, space, s), *bv = to_device(sc, b_vals, nnz_b, space, s);
+    int64_t *ap, *bp;
+    uint32_t *ai, *bi;
+    T *acv, *bcv;
+    coo_to_compressed_device<T>(ctx, sc, K, M, nnz_a, ac, ar, av, "A (COO)", &ap, &ai, &acv);  // csc = coo2csr<true>(A, K)
+    coo_to_compressed_device<T>(ctx, sc, K, N, nnz_b, br, bc, bv, "B (COO)", &bp, &bi, &bcv);  // csr = coo2csr(B, K)
+    OSP_HIP(hipEventRecord(ev1, s));
+    osp_config_t c2 = cfg;
+    c2.validate = 0;  // ordering, ranges and duplicates were just established
+    spgemm_impl<T>(ctx, res, M, K, N, ap, ai, acv, bp, bi, bcv, OSP_DEVICE, c2);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    res->info.ms_ingest = ms;
+    res->info.ms_total += ms;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+}
+
 template <class T>
 static void merge_parts_impl(Context *ctx, Result *res, uint64_t M, uint64_t N, int nparts,
                              const int64_t *const *rowptrs, const uint32_t *const *colidxs, const void *const *valss,
@@ -818,6 +881,44 @@ int osp_spgemm_csc_csr(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, uint64
         else
             spgemm_impl<double>(ctx, res, M, K, N, a_colptr, a_rowidx, (const double *)a_vals, b_rowptr, b_colidx,
                                 (const double *)b_vals, space, cfg);
+    } catch (const Error &e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        destroy_result(res);
+        return fail(e.status, "%s", e.what());
+    } catch (const std::exception &e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        destroy_result(res);
+        return fail(OSP_ERR_ALLOC, "%s", e.what());
+    }
+    *result = (osp_result_t)res;
+    return OSP_OK;
+}
+
+int osp_spgemm_coo(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, uint64_t K, uint64_t N, uint64_t nnz_a,
+                   const uint32_t *a_rows, const uint32_t *a_cols, const void *a_vals, uint64_t nnz_b,
+                   const uint32_t *b_rows, const uint32_t *b_cols, const void *b_vals, osp_memspace_t space,
+                   const osp_config_t *cfg_, osp_result_t *result) {
+    Context *ctx = (Context *)ctx_;
+    if (!ctx || !result) return fail(OSP_ERR_ARG, "null context or result pointer");
+    if ((nnz_a && (!a_rows || !a_cols || !a_vals)) || (nnz_b && (!b_rows || !b_cols || !b_vals))) return fail(OSP_ERR_ARG, "null operand array");
+    if (dtype != OSP_F32 && dtype != OSP_F64) return fail(OSP_ERR_ARG, "dtype must be OSP_F32 or OSP_F64");
+    if (space != OSP_HOST && space != OSP_DEVICE) return fail(OSP_ERR_ARG, "bad memory space");
+    if (M >= 0xffffffffull || N > 0xffffffffull || K >= 0xffffffffull || nnz_a >= 0xffffffffull || nnz_b >= 0xffffffffull)
+        return fail(OSP_ERR_ARG, "dimension or nnz exceeds the u32 index type");
+    osp_config_t cfg;
+    if (cfg_) cfg = *cfg_; else osp_config_default(&cfg);
+    Result *res = new Result;
+    res->ctx = ctx;
+    res->dtype = dtype;
+    res->info.M = M; res->info.K = K; res->info.N = N; res->info.dtype = dtype;
+    try {
+        OSP_HIP(hipSetDevice(ctx->device));
+        if (dtype == OSP_F32)
+            spgemm_coo_impl<float>(ctx, res, M, K, N, nnz_a, a_rows, a_cols, (const float *)a_vals, nnz_b, b_rows, b_cols,
+                                   (const float *)b_vals, space, cfg);
+        else
+            spgemm_coo_impl<double>(ctx, res, M, K, N, nnz_a, a_rows, a_cols, (const double *)a_vals, nnz_b, b_rows, b_cols,
+                                    (const double *)b_vals, space, cfg);
     } catch (const Error &e) {
         (void)hipStreamSynchronize(ctx->stream);
         destroy_result(res);

@@ -145,17 +145,12 @@ int spgemm_mtx_t(osp_context_t ctx, osp_dtype_t dtype, const char *pa, const cha
     }
     if (st == OSP_OK) {
         const uint64_t K = nc[0];
-        std::vector<T> av(nz[0]), bv(nz[1]), acv(nz[0]), bcv(nz[1]);
+        std::vector<T> av(nz[0] ? nz[0] : 1), bv(nz[1] ? nz[1] : 1);
         for (uint64_t i = 0; i < nz[0]; i++) av[i] = (T)vals[0][i];  // value_t(val), :94
         for (uint64_t i = 0; i < nz[1]; i++) bv[i] = (T)vals[1][i];
-        std::vector<int64_t> ap(K + 1), bp(K + 1);
-        std::vector<uint32_t> ai(nz[0] ? nz[0] : 1), bi(nz[1] ? nz[1] : 1);
-        st = coo_to_compressed<T>(1, K, nz[0], rows[0], cols[0], av.data(), ap.data(), ai.data(), acv.data());  // :878
-        if (st == OSP_OK)
-            st = coo_to_compressed<T>(0, K, nz[1], rows[1], cols[1], bv.data(), bp.data(), bi.data(), bcv.data());  // :879
-        if (st == OSP_OK)
-            st = osp_spgemm_csc_csr(ctx, dtype, nr[0], K, nc[1], ap.data(), ai.data(), acv.data(), bp.data(), bi.data(),
-                                    bcv.data(), OSP_HOST, cfg, result);
+        // csc = coo2csr<true>(A), csr = coo2csr(B') (:878-879) and the product, all on the device
+        st = osp_spgemm_coo(ctx, dtype, nr[0], K, nc[1], nz[0], rows[0], cols[0], av.data(), nz[1], rows[1], cols[1], bv.data(),
+                            OSP_HOST, cfg, result);
     }
     for (int i = 0; i < 2; i++) { free(rows[i]); free(cols[i]); free(vals[i]); }
     return st;

@@ -138,14 +138,15 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
 // hist needs rs_hist_entries(n) u32, scan_scratch scan_scratch_entries(rs_hist_entries(n)).
 template <class Epi>
 inline void device_sort_rows(const uint32_t *keys_raw, uint64_t n, int nbits, uint32_t *ka, uint32_t *pa, uint32_t *kb,
-                             uint32_t *pb, uint32_t *hist, uint32_t *scan_scratch, Epi epi, hipStream_t stream) {
+                             uint32_t *pb, uint32_t *hist, uint32_t *scan_scratch, Epi epi, hipStream_t stream,
+                             const uint32_t *vals_raw = nullptr /* payload of keys_raw[i]; default: i itself */) {
     if (n == 0) return;
     const uint32_t nb = rs_blocks(n);
     const int npass = std::max(1, (nbits + 7) / 8);
-    const uint32_t *kin = keys_raw, *pin = nullptr;
+    const uint32_t *kin = keys_raw, *pin = vals_raw;
     uint32_t *kout = ka, *pout = pa;
     for (int p = 0; p < npass; p++) {
-        const bool first = p == 0, last = p == npass - 1;
+        const bool first = p == 0 && vals_raw == nullptr, last = p == npass - 1;
         const int shift = 8 * p;
         if (first) rs_hist_kernel<true><<<nb, kRsThreads, 0, stream>>>(kin, n, shift, hist, nb);
         else rs_hist_kernel<false><<<nb, kRsThreads, 0, stream>>>(kin, n, shift, hist, nb);
@@ -157,6 +158,35 @@ inline void device_sort_rows(const uint32_t *keys_raw, uint64_t n, int nbits, ui
         kin = kout; pin = pout;
         if (kout == ka) { kout = kb; pout = pb; } else { kout = ka; pout = pa; }
     }
+}
+
+// plain epilogue: store the sorted pairs
+struct RsStoreEpilogue {
+    uint32_t *keys_out, *vals_out;
+    __device__ void operator()(uint64_t t, uint32_t k, uint32_t v) const { keys_out[t] = k; vals_out[t] = v; }
+};
+
+// ---- on-device COO -> CSR/CSC (coo2csr<transpose> + dupcheck, SimSpGEMM.cpp:102-152, 43-53) ----------------
+// out[t] = in[perm[t]]
+__global__ void ingest_gather_u32_kernel(const uint32_t *in, const uint32_t *perm, uint64_t n, uint32_t *out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = in[perm[t]];
+}
+// final gather in (segment, inner) order + range check + adjacent-duplicate check (the reference's dupcheck)
+template <class T>
+__global__ void ingest_finish_kernel(const uint32_t *seg_sorted, const uint32_t *perm, const uint32_t *inner, const T *vals,
+                                     uint64_t n, uint64_t nseg, uint64_t ninner, uint32_t *idx, T *out_vals, uint32_t *flags) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t sgm = seg_sorted[t], in = inner[perm[t]];
+    idx[t] = in;
+    out_vals[t] = vals[perm[t]];
+    if (sgm >= nseg || in >= ninner) atomicOr(flags, kFlagRange);
+    if (t > 0 && seg_sorted[t - 1] == sgm && inner[perm[t - 1]] == in) atomicOr(flags, kFlagDuplicate);
+}
+__global__ void ingest_ptr_kernel(const uint32_t *seg_sorted, uint64_t n, uint64_t nseg, int64_t *ptr) {
+    const uint64_t sg = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sg <= nseg) ptr[sg] = (int64_t)lower_bound_dev(seg_sorted, 0, n, sg);
 }
 
 // ---- symbolic epilogue: for the t-th A entry in (row, k) order ------------------------------------

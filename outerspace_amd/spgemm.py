@@ -145,6 +145,21 @@ class Context:
                                                  _lib.OSP_HOST, C.byref(cfg), C.byref(h)))
         return CsrResult(self, h)
 
+    def spgemm_coo(self, M, K, N, a, b, *, partial_capacity=0):
+        """C = A * B from COO triples a = (rows, cols, vals), b = (rows, cols, vals) in any order (numpy, host):
+        ``coo2csr<true>(A)`` / ``coo2csr(B)`` (SimSpGEMM.cpp:102-152) run on the GPU; duplicates raise 233."""
+        dt = np.dtype(a[2].dtype)
+        if dt not in _DT or np.dtype(b[2].dtype) != dt:
+            raise TypeError("values must both be float32 or both float64")
+        arrs = [np.ascontiguousarray(a[0], np.uint32), np.ascontiguousarray(a[1], np.uint32), np.ascontiguousarray(a[2], dt),
+                np.ascontiguousarray(b[0], np.uint32), np.ascontiguousarray(b[1], np.uint32), np.ascontiguousarray(b[2], dt)]
+        cfg = self._config(True, partial_capacity, None)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().osp_spgemm_coo(self._h, _DT[dt], M, K, N, len(arrs[0]), _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]),
+                                             len(arrs[3]), _ptr(arrs[3]), _ptr(arrs[4]), _ptr(arrs[5]), _lib.OSP_HOST,
+                                             C.byref(cfg), C.byref(h)))
+        return CsrResult(self, h)
+
     def spgemm_csc_csr_device(self, dtype, M, K, N, ptrs, *, validate=False, partial_capacity=0, k_range=None):
         """Same with six DEVICE addresses (ints): a_colptr, a_rowidx, a_vals, b_rowptr, b_colidx, b_vals."""
         cfg = self._config(validate, partial_capacity, k_range)

@@ -376,3 +376,35 @@ def test_huge_column_space_and_many_empty_rows(ctx, port):
     b2 = gen.random_coo(K, 1000, 0.02, seed=5)
     got, want = run_both(ctx, port, M2, K, 1000, a2, b2, np.float64)
     assert_same(got, want)
+
+
+def test_device_ingest_coo(ctx, port):
+    """osp_spgemm_coo: COO in any order -> CSC/CSR on the device (coo2csr, SimSpGEMM.cpp:102-152) -> product."""
+    from outerspace_amd import spgemm as S
+    rng = np.random.default_rng(2)
+    n, rows, cols, vals = gen.rmat_coo(12, 12, "g500", seed=6)
+    pa, pb = rng.permutation(len(rows)), rng.permutation(len(rows))           # shuffled input order
+    a = (rows[pa], cols[pa], vals[pa])
+    b = (rows[pb], cols[pb], vals[pb])
+    got = ctx.spgemm_coo(n, n, n, a, b)
+    want = port.spgemm(n, n, n, *S.coo_to_csc(n, rows, cols, vals), *S.coo_to_csr(n, rows, cols, vals))
+    assert_same(got, want)
+    assert got.info["ms_ingest"] > 0
+    # rectangular, f32, with the golden edge case
+    e = load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"), "edges_expected.npz")
+    a = (e["rect_a_rows"], e["rect_a_cols"], e["rect_a_vals"].astype(np.float32))
+    b = (e["rect_b_rows"], e["rect_b_cols"], e["rect_b_vals"].astype(np.float32))
+    got = ctx.spgemm_coo(5, 7, 3, a, b)
+    assert np.array_equal(csr_rows(got.rowptr), e["rect_rows_float32"]) and np.array_equal(got.colidx, e["rect_cols_float32"])
+    assert np.allclose(got.vals, e["rect_vals_float32"], rtol=1e-5, atol=0)
+    # duplicate coordinate -> 233 (reference: throw(233)); index out of range -> 6
+    with pytest.raises(S.OspError) as ei:
+        ctx.spgemm_coo(3, 3, 3, (e["dup_rows"], e["dup_cols"], e["dup_vals"]), (e["dup_rows"][:1], e["dup_cols"][:1], e["dup_vals"][:1]))
+    assert ei.value.status == 233
+    with pytest.raises(S.OspError) as ei:
+        ctx.spgemm_coo(3, 3, 3, (np.array([0, 7], np.uint32), np.array([0, 1], np.uint32), np.array([1.0, 2.0])),
+                       (np.array([0], np.uint32), np.array([0], np.uint32), np.array([1.0])))
+    assert ei.value.status == 6
+    # empty operands
+    z = (np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0))
+    assert ctx.spgemm_coo(4, 5, 6, z, z).nnz == 0
