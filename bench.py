@@ -5,8 +5,10 @@
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # k-sharded
 
 A "step" is one complete product with the operands already resident in HBM: symbolic chunk
-layout, multiply, merge, compaction into CSR (and, for N > 1, the exchange of partial CSRs over
-RCCL and the final per-row merge).  Rank 0 prints ONE JSON line.
+layout, multiply, merge into CSR.  For N > 1 the output rows are sharded over the ranks (`--shard rows`,
+default: no exchange, result row-sharded) or the shared dimension is (`--shard k`: all-to-all-v of partial
+CSRs over RCCL + per-row-range merge).  Every run ends with an untimed whole-result check
+(1^T C 1 = (1^T A)(B 1)).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -39,6 +41,9 @@ def parse():
     ap.add_argument("--partial-capacity", type=int, default=0)
     ap.add_argument("--cpu-baseline", type=int, default=1, help="time the CPU reference on a k-slab (rank 0, N=1)")
     ap.add_argument("--cpu-partials", type=float, default=2.5e8, help="partial products in the CPU sample slab")
+    ap.add_argument("--shard", default="rows", choices=["rows", "k"],
+                    help="multi-GPU decomposition: rows = every rank computes a range of output rows from the replicated "
+                         "operands (no exchange); k = shard the shared dimension, exchange partial CSRs over RCCL, merge")
     ap.add_argument("--force-dist", type=int, default=0, help="run the k-sharded code path even with one rank (sanity check)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal only: exchange staged through host memory, ranks may share a GPU")
@@ -206,7 +211,7 @@ def main():
                                                .sum(dtype=torch.float64))
             res.close()
             return info
-    else:
+    elif args.shard == "k":
         from outerspace_amd import distributed as D
         plan = D.plan_k_shards(csc[0], csr[0], world)
 
@@ -214,6 +219,13 @@ def main():
             return D.spgemm_k_sharded(ctx, np_dtype, n, n, n, csc, csr, plan, dist, rank, world,
                                       partial_capacity=args.partial_capacity,
                                       stage_through_host=args.dist_backend == "gloo", checksum=checksum)
+    else:
+        from outerspace_amd import distributed as D
+
+        def step(checksum=False):
+            return D.spgemm_row_sharded(ctx, np_dtype, n, n, n, ptrs, dist, rank, world, device,
+                                        partial_capacity=args.partial_capacity,
+                                        host_collectives=args.dist_backend == "gloo", checksum=checksum)
 
     for _ in range(args.warmup):
         step()
@@ -273,7 +285,9 @@ def main():
                                     f"duplicates removed, self-product C=A*A, CSC x CSR -> CSR") if args.workload == "rmat" else
                                    "web-Google-shaped synthetic pattern matrix (916428 vertices, power-law degrees), self-product",
                        "n": n, "nnz_a": nnz_a, "partials": P, "nnz_c": nnz_c,
-                       "parallelism": "single GPU" if world == 1 else f"k-sharded over {world} GPUs + RCCL all-to-all of partial CSRs"},
+                       "parallelism": "single GPU" if world == 1 else (
+                           f"k-sharded over {world} GPUs + RCCL all-to-all of partial CSRs" if args.shard == "k" else
+                           f"output rows sharded over {world} GPUs (operands replicated, result row-sharded, no exchange)")},
             "gflops": 2 * P / (ms_step * 1e-3) / 1e9, "partials_per_s": P / (ms_step * 1e-3),
             "phases_ms": {k: mean(k) for k in ("ms_symbolic", "ms_multiply", "ms_merge", "ms_compact", "ms_total")},
             "panels": info["panels"], "long_rows_split": info["heavy_rows"], "long_row_partials": info["heavy_partials"],

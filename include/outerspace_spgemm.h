@@ -65,14 +65,19 @@ typedef struct osp_config {
     uint64_t partial_capacity;  /* max partial products staged in HBM at once (0 = auto);
                                    the product is processed in output-row panels of at most this */
     uint64_t k_begin, k_end;    /* restrict the shared dimension to [k_begin,k_end); k_end = 0
-                                   means K.  This is the multi-GPU shard. */
-    int reserved[8];
+                                   means K.  This is the k-sharded multi-GPU mode. */
+    int row_shard_index;        /* row-sharded multi-GPU mode: compute only output-row range number        */
+    int row_shard_count;        /* `index` of `count` ranges balanced by partial products (count <= 1: all  */
+                                /* rows).  Every rank derives the same ranges from the operands alone: no   */
+                                /* communication.  The result then has row_end - row_begin rows.            */
+    int reserved[6];
 } osp_config_t;
 
 /* What one multiply did.  Times are device milliseconds measured with HIP events on the
  * context's stream. */
 typedef struct osp_result_info {
-    uint64_t M, K, N;
+    uint64_t M, K, N;           /* M = rows of the RESULT (the shard's rows in row-sharded mode) */
+    uint64_t row_begin, row_end;/* output rows this result covers */
     uint64_t nnz_a, nnz_b, nnz_c;
     uint64_t partials;          /* P = sum_k nnz(A[:,k]) * nnz(B[k,:])  (reference mulflops_ref) */
     uint32_t panels;            /* output-row panels processed */

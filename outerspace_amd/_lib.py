@@ -26,11 +26,12 @@ class OspError(RuntimeError):
 
 class Config(C.Structure):
     _fields_ = [("validate", C.c_int), ("partial_capacity", C.c_uint64), ("k_begin", C.c_uint64),
-                ("k_end", C.c_uint64), ("reserved", C.c_int * 8)]
+                ("k_end", C.c_uint64), ("row_shard_index", C.c_int), ("row_shard_count", C.c_int), ("reserved", C.c_int * 6)]
 
 
 class ResultInfo(C.Structure):
     _fields_ = [("M", C.c_uint64), ("K", C.c_uint64), ("N", C.c_uint64),
+                ("row_begin", C.c_uint64), ("row_end", C.c_uint64),
                 ("nnz_a", C.c_uint64), ("nnz_b", C.c_uint64), ("nnz_c", C.c_uint64),
                 ("partials", C.c_uint64), ("panels", C.c_uint32), ("light_tiles", C.c_uint64),
                 ("heavy_rows", C.c_uint64), ("heavy_partials", C.c_uint64),

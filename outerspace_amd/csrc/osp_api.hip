@@ -348,9 +348,16 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
 
 // ---- stages shared by both entry points: partial products of each row -> final CSR ----------------
 template <class T>
-static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_t M, uint64_t N,
+static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_t M_all, uint64_t N,
                            const uint64_t *d_row_off, const uint32_t *d_arow, const uint64_t *d_chunk_start,
-                           uint64_t P, uint64_t cap_cfg, PhaseTimer &tm) {
+                           uint64_t P, uint64_t cap_cfg, PhaseTimer &tm, uint64_t r_lo = 0, uint64_t r_hi = ~0ull,
+                           uint64_t off_lo = 0) {
+    // output rows [r_lo, r_hi) only (row-sharded multi-GPU mode); P = their partial products, off_lo = row_off[r_lo]
+    if (r_hi == ~0ull) r_hi = M_all;
+    const uint64_t M = r_hi - r_lo;
+    res->info.M = M;
+    res->info.row_begin = r_lo;
+    res->info.row_end = r_hi;
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
     // merge algorithm of the LDS tiles: stable 9-bit LSD radix sort (default) or pairwise merging of the
@@ -371,7 +378,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         Scratch us(ctx);
         uint64_t *ub = us.get<uint64_t>(M + 1);
         uint64_t *ub_tmp = us.get<uint64_t>(scan_scratch_entries(M + 1));
-        device_exclusive_scan<RowUpperBound, uint64_t>(RowUpperBound{d_row_off, N}, M, ub, ub_tmp, s);
+        device_exclusive_scan<RowUpperBound, uint64_t>(RowUpperBound{d_row_off + r_lo, N}, M, ub, ub_tmp, s);
         cap_c = d2h(ub + M, s);
     }
     res->colidx = (uint32_t *)ctx->alloc(std::max<uint64_t>(cap_c, 1) * sizeof(uint32_t));
@@ -391,27 +398,29 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         fprintf(stderr, "[osp] M=%llu N=%llu P=%llu nnzC<=%llu (%.1f GB) free %.1f GB -> staging capacity %llu partial products (%.1f GB)\n",
                 (unsigned long long)M, (unsigned long long)N, (unsigned long long)P, (unsigned long long)cap_c, cap_c * E / 1e9,
                 free_b / 1e9, (unsigned long long)cap, cap * E / 1e9);
-    std::vector<uint64_t> bounds{0};
-    std::vector<uint64_t> h_off;
+    std::vector<uint64_t> bounds{r_lo};  // absolute row ids
+    std::vector<uint64_t> h_off_v;         // row_off[r_lo .. r_hi] on the host (multi-panel only)
     if (P <= cap) {
-        bounds.push_back(M);
+        bounds.push_back(r_hi);
     } else {
-        h_off.resize(M + 1);
-        OSP_HIP(hipMemcpyAsync(h_off.data(), d_row_off, (M + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        h_off_v.resize(M + 1);
+        OSP_HIP(hipMemcpyAsync(h_off_v.data(), d_row_off + r_lo, (M + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         OSP_HIP(hipStreamSynchronize(s));
         uint64_t r = 0;
         while (r < M) {
             // largest r1 with row_off[r1] - row_off[r] <= cap
-            uint64_t r1 = std::upper_bound(h_off.begin() + r, h_off.end(), h_off[r] + cap) - h_off.begin() - 1;
+            uint64_t r1 = std::upper_bound(h_off_v.begin() + r, h_off_v.end(), h_off_v[r] + cap) - h_off_v.begin() - 1;
             if (r1 <= r)
-                throw Error(OSP_ERR_CAPACITY, "output row " + std::to_string(r) + " has " +
-                            std::to_string(h_off[r + 1] - h_off[r]) + " partial products, staging capacity is " +
+                throw Error(OSP_ERR_CAPACITY, "output row " + std::to_string(r_lo + r) + " has " +
+                            std::to_string(h_off_v[r + 1] - h_off_v[r]) + " partial products, staging capacity is " +
                             std::to_string(cap));
             r1 = std::min(r1, M);
-            bounds.push_back(r1);
+            bounds.push_back(r_lo + r1);
             r = r1;
         }
     }
+    const uint64_t *h_off = h_off_v.empty() ? nullptr : h_off_v.data() - r_lo;  // indexed by absolute row id
+    const bool all_rows = r_lo == 0 && r_hi == M_all;
     const uint32_t npanels = (uint32_t)bounds.size() - 1;
     res->info.panels = npanels;
     uint64_t max_panel = 0, max_rows_panel = 0;
@@ -426,15 +435,15 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
 
     for (uint32_t p = 0; p < npanels; p++) {
         const uint64_t r0 = bounds[p], r1 = bounds[p + 1];
-        const uint64_t base = (npanels == 1) ? 0 : h_off[r0];
+        const uint64_t base = (npanels == 1) ? off_lo : h_off[r0];
         const uint64_t count = (npanels == 1) ? P : h_off[r1] - base;
         // ---- multiply (or scatter of CSR parts) ----
         tm.begin(PH_MUL);
-        if (count) prod.produce(r0, r1, npanels == 1, base, count, stage, tm);
+        if (count) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm);
         tm.end(PH_MUL);
         // ---- merge ----
         tm.begin(PH_MERGE);
-        MergeIO<T> io{stage, d_row_off, r0, r1, base, res->rowptr, c_col, c_val, out_nnz + p, out_nnz + p + 1};
+        MergeIO<T> io{stage, d_row_off, r0, r1, base, res->rowptr - r_lo, c_col, c_val, out_nnz + p, out_nnz + p + 1};
         merge_panel<T>(ctx, res, tm, io, colbits);
         tm.end(PH_MERGE);
     }
@@ -616,7 +625,23 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     prod.prod = sc.get<uint64_t>(nk); prod.prod_off = sc.get<uint64_t>(nk + 1);
     prod.scan_tmp = sc.get<uint64_t>(scan_scratch_entries(nk));
 
-    merge_pipeline<T>(ctx, res, prod, M, N, row_off, arow, chunk_start, P, cfg.partial_capacity, tm);
+    uint64_t r_lo = 0, r_hi = M, off_lo = 0, P_rows = P;
+    if (cfg.row_shard_count > 1) {
+        // row-sharded multi-GPU mode: this rank's contiguous range of output rows, balanced by partial products
+        if (cfg.row_shard_index < 0 || cfg.row_shard_index >= cfg.row_shard_count) throw Error(OSP_ERR_ARG, "row shard index out of range");
+        const uint32_t G = (uint32_t)cfg.row_shard_count;
+        uint64_t *d_b = sc.get<uint64_t>(2ull * (G + 1));
+        shard_bounds_kernel<<<grid_for(G + 1, 64), 64, 0, s>>>(row_off, M, P, G, d_b, d_b + G + 1);
+        std::vector<uint64_t> h_b(2ull * (G + 1));
+        OSP_HIP(hipMemcpyAsync(h_b.data(), d_b, h_b.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        OSP_HIP(hipStreamSynchronize(s));
+        r_lo = h_b[cfg.row_shard_index];
+        r_hi = h_b[cfg.row_shard_index + 1];
+        off_lo = h_b[G + 1 + cfg.row_shard_index];
+        P_rows = h_b[G + 1 + cfg.row_shard_index + 1] - off_lo;
+        res->info.partials = P_rows;
+    }
+    merge_pipeline<T>(ctx, res, prod, M, N, row_off, arow, chunk_start, P_rows, cfg.partial_capacity, tm, r_lo, r_hi, off_lo);
 
     OSP_HIP(hipEventRecord(ev1, s));
     OSP_HIP(hipStreamSynchronize(s));

@@ -796,10 +796,20 @@ __global__ void heavy_src_inplace_kernel(const uint32_t *rows, uint32_t nheavy, 
 // ---- output bound -------------------------------------------------------------------------------
 // nnz(C) <= sum_i min(U_i, N): capacity of the final CSR arrays
 struct RowUpperBound {
-    const uint64_t *row_off;
+    const uint64_t *row_off;  // already offset to the first row of the range
     uint64_t N;
     __device__ uint64_t operator()(uint64_t r) const { return min(row_off[r + 1] - row_off[r], N); }
 };
+// bounds[j] = first row whose staging offset reaches j/G of all partial products (j = 0..G): row ranges of
+// equal work that every rank computes identically from the operands alone
+__global__ void shard_bounds_kernel(const uint64_t *row_off, uint64_t M, uint64_t P, uint32_t G, uint64_t *bounds, uint64_t *offs) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > G) return;
+    uint64_t r = j == G ? M : lower_bound_dev(row_off, 0, M + 1, (uint64_t)((unsigned __int128)P * j / G));
+    if (r > M) r = M;
+    bounds[j] = r;
+    offs[j] = row_off[r];
+}
 __global__ void set_u64_kernel(uint64_t *p, uint64_t v) { *p = v; }
 
 // ---- CSR parts -> staging (multi-GPU final merge) ----------------------------------

@@ -211,3 +211,27 @@ def spgemm_k_sharded(ctx, np_dtype, M, K, N, csc, csr, k_bounds, dist, rank, wor
     keep["local"].close()
     keep["final"].close()
     return info
+
+
+def spgemm_row_sharded(ctx, np_dtype, M, K, N, ptrs, dist, rank, world, device, partial_capacity=0, host_collectives=False,
+                       checksum=False):
+    """Row-sharded product: rank i computes the i-th of `world` output-row ranges (balanced by partial products, derived
+    by every rank from the replicated operands alone).  No data-path collective; only the counters of the report are
+    all-reduced.  ptrs: the six device addresses of CSC(A) / CSR(B)."""
+    res = ctx.spgemm_csc_csr_device(np_dtype, M, K, N, ptrs, validate=False, partial_capacity=partial_capacity,
+                                    row_shard=(rank, world))
+    info = dict(res.info)
+    cdev = "cpu" if host_collectives else device
+    tot = torch.tensor([info["nnz_c"], info["partials"]], device=cdev, dtype=torch.int64)
+    dist.all_reduce(tot)
+    info.update(nnz_c_global=int(tot[0]), partials_global=int(tot[1]))
+    if checksum:
+        vt = "<f8" if np.dtype(np_dtype) == np.float64 else "<f4"
+        tdt = torch.float64 if np.dtype(np_dtype) == np.float64 else torch.float32
+        _, _, va = res.device_ptrs()
+        vs = _as_tensor(va, res.nnz, vt, device, tdt).sum(dtype=torch.float64).reshape(1)
+        vs = vs.cpu() if host_collectives else vs
+        dist.all_reduce(vs)
+        info["val_sum_global"] = float(vs[0])
+    res.close()
+    return info

@@ -117,18 +117,21 @@ class Context:
         except Exception:
             pass
 
-    def _config(self, validate, partial_capacity, k_range):
+    def _config(self, validate, partial_capacity, k_range, row_shard=None):
         cfg = _lib.Config()
         _lib.lib().osp_config_default(C.byref(cfg))
         cfg.validate = int(bool(validate))
         cfg.partial_capacity = int(partial_capacity or 0)
         if k_range is not None:
             cfg.k_begin, cfg.k_end = int(k_range[0]), int(k_range[1])
+        if row_shard is not None:
+            cfg.row_shard_index, cfg.row_shard_count = int(row_shard[0]), int(row_shard[1])
         return cfg
 
     def spgemm_csc_csr(self, M, K, N, a_colptr, a_rowidx, a_vals, b_rowptr, b_colidx, b_vals, *,
-                       validate=True, partial_capacity=0, k_range=None):
-        """C = A(CSC) * B(CSR) with numpy (host) operands."""
+                       validate=True, partial_capacity=0, k_range=None, row_shard=None):
+        """C = A(CSC) * B(CSR) with numpy (host) operands.  row_shard=(i, G): only the i-th of G output-row ranges
+        (balanced by partial products; ``result.info['row_begin'/'row_end']`` say which rows came back)."""
         dt = np.dtype(a_vals.dtype)
         if dt not in _DT or np.dtype(b_vals.dtype) != dt:
             raise TypeError("values must both be float32 or both float64")
@@ -139,7 +142,7 @@ class Context:
             # reference: assert(csc.pos.size() == csr.pos.size()), SimSpGEMM.cpp:267
             raise OspError(_lib.ERR_DIM, f"pointer arrays must have K+1={K + 1} entries "
                                          f"(got {len(arrs[0])} and {len(arrs[3])})")
-        cfg = self._config(validate, partial_capacity, k_range)
+        cfg = self._config(validate, partial_capacity, k_range, row_shard)
         h = C.c_void_p()
         _lib.check(_lib.lib().osp_spgemm_csc_csr(self._h, _DT[dt], M, K, N, *[_ptr(a) for a in arrs],
                                                  _lib.OSP_HOST, C.byref(cfg), C.byref(h)))
@@ -160,9 +163,9 @@ class Context:
                                              C.byref(cfg), C.byref(h)))
         return CsrResult(self, h)
 
-    def spgemm_csc_csr_device(self, dtype, M, K, N, ptrs, *, validate=False, partial_capacity=0, k_range=None):
+    def spgemm_csc_csr_device(self, dtype, M, K, N, ptrs, *, validate=False, partial_capacity=0, k_range=None, row_shard=None):
         """Same with six DEVICE addresses (ints): a_colptr, a_rowidx, a_vals, b_rowptr, b_colidx, b_vals."""
-        cfg = self._config(validate, partial_capacity, k_range)
+        cfg = self._config(validate, partial_capacity, k_range, row_shard)
         h = C.c_void_p()
         _lib.check(_lib.lib().osp_spgemm_csc_csr(self._h, _DT[np.dtype(dtype)], M, K, N,
                                                  *[C.c_void_p(int(p)) for p in ptrs], _lib.OSP_DEVICE,

@@ -408,3 +408,24 @@ def test_device_ingest_coo(ctx, port):
     # empty operands
     z = (np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0))
     assert ctx.spgemm_coo(4, 5, 6, z, z).nnz == 0
+
+
+def test_row_shards_tile_the_product(ctx, port):
+    """Row-sharded multi-GPU mode: G results with disjoint, contiguous row ranges that concatenate to the full CSR
+    (bit-exact), ranges balanced by partial products and derived identically by every rank."""
+    n, rows, cols, vals = gen.rmat_coo(13, 12, "mild", seed=8)
+    got_full, want = run_both(ctx, port, n, n, n, (rows, cols, vals), (rows, cols, vals), np.float64)
+    from outerspace_amd import spgemm as S
+    acsc, bcsr = S.coo_to_csc(n, rows, cols, vals), S.coo_to_csr(n, rows, cols, vals)
+    for G in (2, 3, 8):
+        end, P = 0, 0
+        for i in range(G):
+            r = ctx.spgemm_csc_csr(n, n, n, *acsc, *bcsr, row_shard=(i, G), partial_capacity=want["partials"] // 5)
+            r0, r1 = r.info["row_begin"], r.info["row_end"]
+            assert r0 == end and r.shape[0] == r1 - r0
+            lo, hi = want["rowptr"][r0], want["rowptr"][r1]
+            assert np.array_equal(r.rowptr, want["rowptr"][r0:r1 + 1] - lo)
+            assert np.array_equal(r.colidx, want["colidx"][lo:hi]) and np.array_equal(r.vals, want["vals"][lo:hi])
+            assert r.info["partials"] <= want["partials"] / G * 1.5 + 5000  # balanced by work
+            end, P = r1, P + r.info["partials"]
+        assert end == n and P == want["partials"]
