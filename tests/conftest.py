@@ -12,6 +12,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the in-tree library is a build product (git-ignored): build it once if a fresh checkout lacks it
+    lib = os.path.join(ROOT, "outerspace_amd", "libouterspace_spgemm.so")
+    cli = os.path.join(ROOT, "outerspace_amd", "osp_spgemm")
+    if not (os.path.exists(lib) and os.path.exists(cli)):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "outerspace_amd", "csrc"), "all"], check=True,
+                       stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")
