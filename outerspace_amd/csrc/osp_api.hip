@@ -260,7 +260,9 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         uint64_t *nhist = sc.get<uint64_t>(nlong);
         uint64_t *blkbase = sc.get<uint64_t>((uint64_t)nlong + 1), *hbase = sc.get<uint64_t>((uint64_t)nlong + 1);
         vbase = sc.get<uint64_t>((uint64_t)nlong + 1);
-        split_params_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(p0.long_rows, nlong, io.row_off, colbits, hbits, nstretch, nseg, nhist);
+        // debugging aid: OSP_SPLIT_ROW_MAX moves the boundary between the two split kernels (tests run both on small inputs)
+        const uint64_t row_max = getenv("OSP_SPLIT_ROW_MAX") ? strtoull(getenv("OSP_SPLIT_ROW_MAX"), nullptr, 10) : kSplitRowMax;
+        split_params_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(p0.long_rows, nlong, io.row_off, colbits, row_max, hbits, nstretch, nseg, nhist);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nstretch}, nlong, blkbase, hscan_tmp, s);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nseg}, nlong, vbase, hscan_tmp, s);
         device_exclusive_scan<LoadU64, uint64_t>(LoadU64{nhist}, nlong, hbase, hscan_tmp, s);
@@ -272,15 +274,21 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
                     (unsigned long long)r0, (unsigned long long)r1, p0.ntiles, nlong, (unsigned long long)nh, (unsigned long long)nvirt);
         uint32_t *ghist = sc.get<uint32_t>(ncell + 1);
         uint32_t *ghist_tmp = sc.get<uint32_t>(scan_scratch_entries(ncell + 1));
-        split_count_kernel<<<(unsigned)nblocks, kSplitThreads, 0, s>>>(p0.long_rows, nlong, blkbase, hbase, hbits, nstretch, io.row_off,
-                                                                     base, colbits, (const char *)io.stage, (uint32_t)sizeof(Part<T>), ghist);
-        device_exclusive_scan<LoadU32, uint32_t>(LoadU32{ghist}, ncell, ghist, ghist_tmp, s);
         qstage = sc.get<Part<T>>(nh);
-        split_scatter_kernel<T><<<(unsigned)nblocks, kSplitThreads, 0, s>>>(p0.long_rows, nlong, blkbase, hbase, hbits, nstretch,
-                                                                          io.row_off, base, colbits, io.stage, ghist, qstage);
         uint64_t *vrow_off = sc.get<uint64_t>(nvirt + 1);
         uint8_t *vfirst = sc.get<uint8_t>(nvirt + 1);
-        split_vrows_kernel<<<grid_for(nvirt + 1, 256), 256, 0, s>>>(nlong, vbase, hbase, nstretch, ghist, nvirt, nh, vrow_off, vfirst);
+        // rows up to kSplitRowMax: one workgroup each (histogram, scan and scatter in one kernel)
+        split_row_kernel<T><<<nlong, kSplitThreads, 0, s>>>(p0.long_rows, nlong, hbits, nstretch, vbase, hoff, io.row_off, base, colbits,
+                                                            io.stage, qstage, vrow_off);
+        if (nblocks) {  // longer rows: one workgroup per 4096-entry stretch, offsets from a device-wide scan
+            split_count_kernel<<<(unsigned)nblocks, kSplitThreads, 0, s>>>(p0.long_rows, nlong, blkbase, hbase, hbits, nstretch, io.row_off,
+                                                                         base, colbits, (const char *)io.stage, (uint32_t)sizeof(Part<T>), ghist);
+            device_exclusive_scan<LoadU32, uint32_t>(LoadU32{ghist}, ncell, ghist, ghist_tmp, s);
+            split_scatter_kernel<T><<<(unsigned)nblocks, kSplitThreads, 0, s>>>(p0.long_rows, nlong, blkbase, hbase, hbits, nstretch,
+                                                                              io.row_off, base, colbits, io.stage, ghist, hoff, qstage);
+        }
+        split_vrows_kernel<<<grid_for(nvirt + 1, 256), 256, 0, s>>>(nlong, vbase, hbase, nstretch, ghist, hoff, nvirt, nh, vrow_off, vfirst);
+        OSP_HIP(hipGetLastError());
         // ---- tiles over the segments; a tile never spans two long rows ----
         p1 = plan_tiles(ctx, sc, vrow_off, 0, nvirt, 0, kCap, max_rows, vfirst);
         vptr = (int64_t *)sc.get<uint64_t>(nvirt + 1);

@@ -19,10 +19,12 @@ constexpr int kSplitThreads = 256;
 constexpr int kSplitStretch = 4096;   // entries of one long row handled by one workgroup
 constexpr int kSplitMaxBits = 12;     // at most 4096 segments per row
 constexpr int kSplitTarget = 256;     // aim for segments of about this many entries
+constexpr uint64_t kSplitRowMax = 1u << 18;  // rows up to this long are split by ONE workgroup (count + scatter,
+                                             // second read from L2); longer rows use one workgroup per stretch
 
 // per long row h: b = number of split bits, and the sizes that get scanned
 __global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *row_off, int colbits,
-                                    uint8_t *hbits, uint32_t *nstretch, uint32_t *nseg, uint64_t *nhist) {
+                                    uint64_t row_max, uint8_t *hbits, uint32_t *nstretch, uint32_t *nseg, uint64_t *nhist) {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= nheavy) return;
     const uint64_t U = row_off[rows[h] + 1] - row_off[rows[h]];
@@ -30,7 +32,8 @@ __global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const
     int b = 1;
     while (b < kSplitMaxBits && (1ull << b) < want) b++;
     b = min(b, colbits);
-    const uint32_t ns = (uint32_t)((U + kSplitStretch - 1) / kSplitStretch);
+    const bool big = U > row_max;
+    const uint32_t ns = big ? (uint32_t)((U + kSplitStretch - 1) / kSplitStretch) : 0u;  // 0 stretches = one-workgroup row
     hbits[h] = (uint8_t)b;
     nstretch[h] = ns;
     nseg[h] = 1u << b;
@@ -99,7 +102,7 @@ template <class T>
 __global__ __launch_bounds__(kSplitThreads) void split_scatter_kernel(
     const uint32_t *rows, uint32_t nheavy, const uint64_t *blkbase, const uint64_t *hbase, const uint8_t *hbits,
     const uint32_t *nstretch, const uint64_t *row_off, uint64_t base, int colbits, const Part<T> *stage,
-    const uint32_t *goffs, Part<T> *qstage) {
+    const uint32_t *goffs, const uint64_t *hoff, Part<T> *qstage) {
     constexpr int NW = kSplitThreads / kWave;
     constexpr int ITERS = kSplitStretch / kSplitThreads;  // 16 wave iterations per wave span
     __shared__ uint16_t cnt[NW][1 << kSplitMaxBits];
@@ -107,8 +110,9 @@ __global__ __launch_bounds__(kSplitThreads) void split_scatter_kernel(
     const SplitJob j = split_job(rows, nheavy, blkbase, hbase, hbits, nstretch, row_off, base);
     const uint32_t nseg = 1u << j.b;
     const unsigned lane = lane_id(), w = threadIdx.x >> 6;
+    const uint32_t qrow = (uint32_t)hoff[j.h] - goffs[j.hbase];  // the scan covers the multi-workgroup rows only
     for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) {
-        boff[d] = goffs[j.hbase + (uint64_t)d * j.nst + j.st];
+        boff[d] = qrow + goffs[j.hbase + (uint64_t)d * j.nst + j.st];
 #pragma unroll
         for (int ww = 0; ww < NW; ww++) cnt[ww][d] = 0;
     }
@@ -159,15 +163,107 @@ __global__ __launch_bounds__(kSplitThreads) void split_scatter_kernel(
 
 // segment v of the split = "virtual row": its offset in the second buffer
 __global__ void split_vrows_kernel(uint32_t nheavy, const uint64_t *vbase, const uint64_t *hbase, const uint32_t *nstretch,
-                                   const uint32_t *goffs, uint64_t nvirt, uint64_t nh_total, uint64_t *vrow_off,
-                                   uint8_t *vfirst) {
+                                   const uint32_t *goffs, const uint64_t *hoff, uint64_t nvirt, uint64_t nh_total,
+                                   uint64_t *vrow_off, uint8_t *vfirst) {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v > nvirt) return;
     if (v == nvirt) { vrow_off[v] = nh_total; vfirst[v] = 1; return; }
     const uint32_t h = (uint32_t)(upper_bound_dev(vbase, 0, (uint64_t)nheavy + 1, v) - 1);
     const uint64_t d = v - vbase[h];
-    vrow_off[v] = goffs[hbase[h] + d * nstretch[h]];
     vfirst[v] = d == 0;  // first segment of a long row: a tile must start here
+    if (nstretch[h] == 0) return;  // one-workgroup row: split_row_kernel wrote its segment offsets
+    vrow_off[v] = hoff[h] + (goffs[hbase[h] + d * nstretch[h]] - goffs[hbase[h]]);
+}
+
+// One workgroup splits one long row of at most kSplitRowMax entries: histogram over its segments, scan, stable
+// scatter -- the row is read twice, the second time from L2.  No global histogram, no device-wide scan.
+template <class T>
+__global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
+    const uint32_t *rows, uint32_t nheavy, const uint8_t *hbits, const uint32_t *nstretch, const uint64_t *vbase,
+    const uint64_t *hoff, const uint64_t *row_off, uint64_t base, int colbits, const Part<T> *stage, Part<T> *qstage,
+    uint64_t *vrow_off) {
+    constexpr int NW = kSplitThreads / kWave;
+    constexpr int ITERS = kSplitStretch / kSplitThreads;
+    __shared__ uint16_t cnt[NW + 1][1 << kSplitMaxBits];
+    __shared__ uint32_t segoff[1 << kSplitMaxBits];  // histogram, then running offset of every segment
+    __shared__ uint32_t scratch[NW + 1];
+    const uint32_t h = blockIdx.x;
+    if (h >= nheavy || nstretch[h] != 0) return;
+    const unsigned lane = lane_id(), w = threadIdx.x >> 6;
+    const uint32_t b = hbits[h], nseg = 1u << b;
+    const int sh = colbits - (int)b;
+    const uint64_t beg = row_off[rows[h]] - base, end = row_off[rows[h] + 1] - base;
+    const uint64_t qbase = hoff[h];
+    for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) segoff[d] = 0;
+    __syncthreads();
+    for (uint64_t i = beg + threadIdx.x; i < end; i += kSplitThreads) atomicAdd(&segoff[stage[i].col >> sh], 1u);
+    __syncthreads();
+    {   // exclusive scan of the segment counts (16 per thread), segment offsets out
+        constexpr int PER = (1 << kSplitMaxBits) / kSplitThreads;
+        uint32_t c[PER], sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; q++) { const uint32_t d = threadIdx.x * PER + q; c[q] = d < nseg ? segoff[d] : 0u; sum += c[q]; }
+        uint32_t total;
+        uint32_t ex = block_excl_scan<uint32_t, kSplitThreads>(sum, scratch, &total);
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const uint32_t d = threadIdx.x * PER + q;
+            if (d < nseg) { segoff[d] = ex; vrow_off[vbase[h] + d] = qbase + ex; }
+            ex += c[q];
+        }
+    }
+    __syncthreads();
+    for (uint64_t sb = beg; sb < end; sb += kSplitStretch) {
+        const uint64_t se = min(sb + (uint64_t)kSplitStretch, end);
+        for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) {
+#pragma unroll
+            for (int ww = 0; ww < NW; ww++) cnt[ww][d] = 0;
+        }
+        __syncthreads();  // also orders the segoff update of the previous round before this round's scatter
+        const uint64_t wbeg = sb + (uint64_t)w * (kSplitStretch / NW);
+        uint32_t kc[ITERS], rk[ITERS];
+        T kv[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
+            kc[it] = 0; kv[it] = 0;
+            if (i < se) { const Part<T> pp = stage[i]; kc[it] = pp.col; kv[it] = pp.val; }
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
+            const bool valid = i < se;
+            const unsigned d = kc[it] >> sh;
+            unsigned r, c;
+            wave_match_bits(d, (int)b, valid, r, c);
+            rk[it] = 0;
+            if (valid) {
+                const uint32_t cur = cnt[w][d];
+                rk[it] = cur + r;
+                if (r == 0) cnt[w][d] = (uint16_t)(cur + c);
+            }
+        }
+        __syncthreads();
+        // per segment: exclusive offsets of the waves inside this stretch; cnt[NW] keeps the stretch's total
+        for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int ww = 0; ww < NW; ww++) { const uint32_t c = cnt[ww][d]; cnt[ww][d] = (uint16_t)run; run += c; }
+            cnt[NW][d] = (uint16_t)run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
+            if (i < se) {
+                const unsigned d = kc[it] >> sh;
+                qstage[qbase + segoff[d] + cnt[w][d] + rk[it]] = Part<T>{kc[it], kv[it]};
+            }
+        }
+        __syncthreads();
+        for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) segoff[d] += cnt[NW][d];
+        // (the zeroing of cnt at the top of the next round touches the same d from the same thread)
+    }
 }
 // merged long row h: its entry count and where it sits in the temporary output
 __global__ void split_rows_done_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *vbase, const int64_t *vptr,

@@ -162,6 +162,21 @@ def test_many_long_rows(ctx, port):
     assert_same(got, want)
 
 
+@pytest.mark.parametrize("row_max", ["0", "6000", None])
+def test_long_row_split_kernels_agree(ctx, port, monkeypatch, row_max):
+    """Long rows are split either by one workgroup per row or by one workgroup per 4096-entry stretch
+    (rows above 2^18 partial products); OSP_SPLIT_ROW_MAX moves the boundary so both run here: all rows
+    on the per-stretch path, a mix, all on the per-row path.  Same bits every time."""
+    if row_max is not None:
+        monkeypatch.setenv("OSP_SPLIT_ROW_MAX", row_max)
+    for dt in (np.float64, np.float32):
+        n, rows, cols, vals = gen.rmat_coo(13, 16, "g500", seed=5, dtype=dt)
+        got, want = run_both(ctx, port, n, n, n, (rows, cols, vals), (rows, cols, vals), dt)
+        assert got.info["heavy_rows"] > 100
+        assert np.array_equal(got.rowptr, want["rowptr"]) and np.array_equal(got.colidx, want["colidx"])
+        assert np.array_equal(got.vals, want["vals"])
+
+
 @pytest.mark.parametrize("preset,scale", [("uniform", 12), ("mild", 12), ("g500", 12)])
 def test_rmat_vs_oracle(ctx, port, preset, scale):
     n, rows, cols, vals = gen.rmat_coo(scale, 16, preset, seed=1)

@@ -90,6 +90,16 @@ float run(uint32_t *tile_rows, uint32_t ntiles, uint64_t M, uint64_t *row_off, u
     return ms;
 }
 
+__global__ void checksum_kernel(const int64_t *rowptr, uint64_t M, const uint32_t *ccol, const double *cval, uint64_t nnz,
+                                unsigned long long *out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long h = 0;
+    if (i <= M) h += (unsigned long long)rowptr[i] * 0x9E3779B97F4A7C15ull + i;
+    if (i < nnz) h += ((unsigned long long)ccol[i] + 1) * (0xBF58476D1CE4E5B9ull ^ i) + (unsigned long long)__double_as_longlong(cval[i]);
+    for (int d = 32; d > 0; d >>= 1) h += __shfl_down(h, d, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
+}
+
 int main(int argc, char **argv) {
     const uint32_t rowlen = argc > 1 ? atoi(argv[1]) : 256;
     const uint32_t rpt = argc > 2 ? atoi(argv[2]) : 9;          // rows per tile
@@ -123,6 +133,24 @@ int main(int argc, char **argv) {
         {"radix NT512 full", run<512, 0>}, {"radix NT512 nosort", run<512, 1>}, {"radix NT512 nolb", run<512, 2>},
         {"radix NT512 nosort+nolb", run<512, 3>}, {"runs NT1024 full", run_runs<1024, 0>},
     };
+    if (getenv("CHECK_GRIDS")) {
+        // the output must not depend on how many workgroups run or in which order they take tickets
+        unsigned long long *d_sum; CK(hipMalloc(&d_sum, 8));
+        unsigned long long ref = 0; uint64_t ref_total = 0;
+        for (uint32_t g : {512u, 1u, 7u, 64u, 511u, 513u, 1000u, 4096u, 100000u}) {
+            g_grid = g;
+            float ms = run<512, 0>(ARGS);
+            uint64_t h_out[2]; CK(hipMemcpy(h_out, outn, 16, hipMemcpyDeviceToHost));
+            CK(hipMemset(d_sum, 0, 8));
+            const uint64_t n = std::max<uint64_t>(M + 1, h_out[1]);
+            checksum_kernel<<<(unsigned)((n + 255) / 256), 256>>>(rowptr, M, ccol, cval, h_out[1], d_sum);
+            unsigned long long hs; CK(hipMemcpy(&hs, d_sum, 8, hipMemcpyDeviceToHost));
+            if (g == 512u) { ref = hs; ref_total = h_out[1]; }
+            printf("grid %6u: %8.3f ms  nnz %llu  checksum %016llx  %s\n", g, ms, (unsigned long long)h_out[1], hs,
+                   (hs == ref && h_out[1] == ref_total) ? "same" : "DIFFERENT");
+        }
+        g_grid = 512;
+    }
     std::vector<std::vector<float>> t(vs.size());
     for (int round = 0; round < 5; round++)
         for (size_t v = 0; v < vs.size(); v++) t[v].push_back(vs[v].fn(ARGS));
