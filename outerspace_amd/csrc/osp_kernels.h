@@ -38,6 +38,24 @@ struct __attribute__((packed, aligned(4))) Part {
     T val;
 };
 
+// A record as it sits in registers right after the load: raw 32-bit words.  Unpacking a 12-byte record into
+// (col, aligned 64-bit val) moves registers, and the compiler waits for the load at that move -- a batch of
+// loads written as `Part<T> p = stage[i]` degenerates into a chain of HBM round trips (seen in the ISA: one
+// s_waitcnt vmcnt(0) per load).  So batches are loaded raw and unpacked where they are used.
+template <class T>
+struct __attribute__((packed, aligned(4))) PartWords {
+    uint32_t w[sizeof(Part<T>) / 4];
+    __device__ __forceinline__ uint32_t col() const { return w[0]; }
+    __device__ __forceinline__ T val() const {
+        if constexpr (sizeof(T) == 8) return (T)__hiloint2double((int)w[2], (int)w[1]);
+        else return (T)__uint_as_float(w[1]);
+    }
+};
+template <class T>
+__device__ __forceinline__ PartWords<T> load_part_words(const Part<T> *p) { return *reinterpret_cast<const PartWords<T> *>(p); }
+template <class T>
+__device__ __forceinline__ void store_part_words(Part<T> *p, const PartWords<T> &r) { *reinterpret_cast<PartWords<T> *>(p) = r; }
+
 // error flag bits written by validate kernels
 constexpr uint32_t kFlagRange = 1u, kFlagUnsorted = 2u, kFlagDuplicate = 4u, kFlagPtr = 8u;
 
@@ -461,6 +479,19 @@ __global__ void chain_finish_kernel(const uint32_t *heavy_rows, uint32_t nlong, 
     if (h == 0) c_rowptr[r_end] = (int64_t)*out_end;
 }
 
+// Phase timing for tools/bench_merge.hip (-DOSP_MERGE_PROF): thread 0 of every workgroup adds the cycles between
+// marks to osp_merge_prof[phase].  Compiled out of the library.
+#ifdef OSP_MERGE_PROF
+__device__ unsigned long long osp_merge_prof[16];
+#define OSP_PROF_DECL unsigned long long prof_acc[12] = {0}; unsigned long long prof_t = clock64();
+#define OSP_PROF_MARK(k) do { if (tid == 0) { const unsigned long long now_ = clock64(); prof_acc[k] += now_ - prof_t; prof_t = now_; } } while (0)
+#define OSP_PROF_FLUSH do { if (tid == 0) for (int k_ = 0; k_ < 12; k_++) atomicAdd(&osp_merge_prof[k_], prof_acc[k_]); } while (0)
+#else
+#define OSP_PROF_DECL
+#define OSP_PROF_MARK(k)
+#define OSP_PROF_FLUSH
+#endif
+
 // ABL: ablation switches for tools/bench_merge.hip only (1 = no sort, 2 = no look-back, 4 = no ticket);
 // the library always instantiates ABL = 0.
 //
@@ -497,8 +528,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
     uint32_t t = s_tnext;
     TileDesc d = s_dnext;
     uint64_t ro = 0;
-    uint32_t lc[LPT];
-    T lv[LPT];
+    PartWords<T> lrec[LPT];  // raw: unpacked at staging time, so the loads stay in flight together
     auto request = [&](const TileDesc &dd, bool ok) {
         const bool fetch = ok && dd.n <= (uint32_t)kTileCap;
         ro = 0;
@@ -507,12 +537,15 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
 #pragma unroll
         for (int q = 0; q < LPT; q++) {
             const uint32_t i = tid + q * NT;
-            lc[q] = 0; lv[q] = 0;
-            if (fetch && i < dd.n) { const Part<T> pp = stage[dd.s + i]; lc[q] = pp.col; lv[q] = pp.val; }
+            // unconditional load from a clamped address (lanes past the end read the descriptor array and
+            // ignore it): a branch here makes the compiler wait for every load inside its own block
+            const Part<T> *src = (fetch && i < dd.n) ? &stage[dd.s + i] : reinterpret_cast<const Part<T> *>(desc);
+            lrec[q] = load_part_words(src);
         }
     };
     request(d, t < ntiles);
     __syncthreads();  // everybody holds t / d before the slots are refilled
+    OSP_PROF_DECL
     while (t < ntiles) {
         const uint64_t ra = d.ra, s = d.s, base = lvl.base[d.lvl];
         const uint32_t nr = d.nr, n = d.n;
@@ -559,6 +592,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
         }
         if (tid <= nr) sm.rowo[tid] = (uint32_t)(ro - base - s);
         __syncthreads();
+        OSP_PROF_MARK(0);
         // stage: key = (local row << colbits) | col; the payload (staging position) is implicit until pass 0
         uint32_t fresh = 0;
 #pragma unroll
@@ -567,9 +601,9 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
             if (i < n) {
                 uint32_t lo = 0, hi = nr;  // last r with rowo[r] <= i
                 while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sm.rowo[mid] <= i) lo = mid; else hi = mid; }
-                const uint32_t k = (colbits < 32 ? (lo << colbits) : 0u) | lc[q];
+                const uint32_t k = (colbits < 32 ? (lo << colbits) : 0u) | lrec[q].col();
                 sm.key[0][i] = k;
-                sm.val[i] = lv[q];
+                sm.val[i] = lrec[q].val();
                 if (early) {
                     uint32_t h = (uint32_t)(((uint64_t)(k * 2654435761u) * HS) >> 32);
                     while (true) {
@@ -585,6 +619,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
             const uint32_t wsum = wave_reduce_sum(fresh);
             if (lane == 0 && wsum) atomicAdd(&sm.hcount, wsum);
             __syncthreads();
+            OSP_PROF_MARK(1);
             if (tid == 0) lookback_publish(tile_status, t, sm.hcount);
         }
         // each wave ranks a contiguous span, so earlier waves = earlier positions (stable)
@@ -592,6 +627,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
         const uint32_t wbeg = min(w * per, n), wend = min(wbeg + per, n);
         int cur = 0;
         __syncthreads();
+        OSP_PROF_MARK(2);
         const int npass = (nbits + kDigitBits - 1) / kDigitBits;
         const int pbits = npass ? (nbits + npass - 1) / npass : 0;  // balanced digit width (<= kDigitBits)
         const uint32_t dmask = (1u << pbits) - 1u;
@@ -615,6 +651,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
                 }
             }
             __syncthreads();
+            OSP_PROF_MARK(3);
             // (b) exclusive scan over (digit major, wave minor); thread dg owns digit dg
             {
                 uint32_t c[NW], ssum = 0;
@@ -630,6 +667,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
                 }
             }
             __syncthreads();
+            OSP_PROF_MARK(4);
             // (c) scatter
 #pragma unroll
             for (int it = 0; it < ITERS; it++) {
@@ -643,6 +681,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
             }
             cur ^= 1;
             __syncthreads();
+            OSP_PROF_MARK(5);
         }
         if (npass == 0) {  // nothing was sorted (empty tile): the payload is still implicit
             for (uint32_t i = tid; i < n; i += NT) sm.pos[0][i] = (uint16_t)i;
@@ -662,6 +701,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
         }
         uint32_t total;
         uint32_t ex = block_excl_scan<uint32_t, NT>(heads, sm.scratch, &total);
+        OSP_PROF_MARK(6);
         // the tile's unique count is known: wave 0 runs the look-back and then requests the next ticket;
         // the ticket's round trip overlaps the run sums below
         if (w == 0) {
@@ -673,6 +713,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
                 tn_reg = (ABL & 4) ? t + gridDim.x : atomicAdd(ticket, 1u);
             }
         }
+        OSP_PROF_MARK(7);
         uint32_t oslot[IPT];
 #pragma unroll
         for (int q = 0; q < IPT; q++) {
@@ -701,6 +742,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
         }
         if (tid == 0) s_tnext = tn_reg;
         __syncthreads();  // all gathers from val[] / key[cur] done; sm.excl and s_tnext are published
+        OSP_PROF_MARK(8);
         // compact into LDS (val[] and the idle key buffer), then stream out with consecutive lanes on
         // consecutive addresses
 #pragma unroll
@@ -710,6 +752,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
         }
         if (tid == 0 && tn_reg < ntiles) s_dnext = desc[tn_reg];
         __syncthreads();
+        OSP_PROF_MARK(9);
         const uint32_t tn = s_tnext;
         const TileDesc dn = s_dnext;
         // the next tile's HBM reads go out ahead of this tile's writes
@@ -722,7 +765,9 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
         t = tn;
         d = dn;
         __syncthreads();  // LDS is reused by the next tile
+        OSP_PROF_MARK(10);
     }
+    OSP_PROF_FLUSH;
 }
 
 // ---- merge: global-sort path for rows longer than kTileCap ---------------------------------------

@@ -19,8 +19,8 @@ constexpr int kSplitThreads = 256;
 constexpr int kSplitStretch = 4096;   // entries of one long row handled by one workgroup
 constexpr int kSplitMaxBits = 12;     // at most 4096 segments per row
 constexpr int kSplitTarget = 256;     // aim for segments of about this many entries
-constexpr uint64_t kSplitRowMax = 1u << 18;  // rows up to this long are split by ONE workgroup (count + scatter,
-                                             // second read from L2); longer rows use one workgroup per stretch
+constexpr int kSplitRowBits = 8;      // rows of at most 2^8 segments (<= 64K entries) are split by ONE workgroup
+constexpr uint64_t kSplitRowMax = (uint64_t)kSplitTarget << kSplitRowBits;  // longer rows: one workgroup per stretch
 
 // per long row h: b = number of split bits, and the sizes that get scanned
 __global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *row_off, int colbits,
@@ -32,7 +32,7 @@ __global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const
     int b = 1;
     while (b < kSplitMaxBits && (1ull << b) < want) b++;
     b = min(b, colbits);
-    const bool big = U > row_max;
+    const bool big = U > row_max || b > kSplitRowBits;
     const uint32_t ns = big ? (uint32_t)((U + kSplitStretch - 1) / kSplitStretch) : 0u;  // 0 stretches = one-workgroup row
     hbits[h] = (uint8_t)b;
     nstretch[h] = ns;
@@ -120,20 +120,18 @@ __global__ __launch_bounds__(kSplitThreads) void split_scatter_kernel(
     const int sh = colbits - (int)j.b;
     // each wave owns a contiguous quarter of the stretch: earlier waves = earlier entries (stable)
     const uint64_t wbeg = j.beg + (uint64_t)w * (kSplitStretch / NW);
-    uint32_t kc[ITERS], rk[ITERS];
-    T kv[ITERS];
+    uint32_t rk[ITERS];
+    PartWords<T> rec[ITERS];  // raw records: all loads in flight together
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
-        const bool valid = i < j.end;
-        kc[it] = 0; kv[it] = 0;
-        if (valid) { const Part<T> pp = stage[i]; kc[it] = pp.col; kv[it] = pp.val; }
+        rec[it] = load_part_words(&stage[i < j.end ? i : j.beg]);  // branch-free: lanes past the end re-read the first record
     }
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
         const bool valid = i < j.end;
-        const unsigned d = kc[it] >> sh;
+        const unsigned d = rec[it].col() >> sh;
         unsigned r, c;
         wave_match_bits(d, (int)j.b, valid, r, c);
         if (valid) {
@@ -154,9 +152,9 @@ __global__ __launch_bounds__(kSplitThreads) void split_scatter_kernel(
     for (int it = 0; it < ITERS; it++) {
         const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
         if (i < j.end) {
-            const unsigned d = kc[it] >> sh;
+            const unsigned d = rec[it].col() >> sh;
             const uint32_t dst = boff[d] + cnt[w][d] + rk[it];
-            qstage[dst] = Part<T>{kc[it], kv[it]};
+            store_part_words(&qstage[dst], rec[it]);
         }
     }
 }
@@ -184,8 +182,10 @@ __global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
     uint64_t *vrow_off) {
     constexpr int NW = kSplitThreads / kWave;
     constexpr int ITERS = kSplitStretch / kSplitThreads;
-    __shared__ uint16_t cnt[NW + 1][1 << kSplitMaxBits];
-    __shared__ uint32_t segoff[1 << kSplitMaxBits];  // histogram, then running offset of every segment
+    constexpr int NSEG = 1 << kSplitRowBits;
+    static_assert(NSEG <= kSplitThreads, "one thread per segment in the scan");
+    __shared__ uint16_t cnt[NW + 1][NSEG];
+    __shared__ uint32_t segoff[NSEG];  // histogram, then running offset of every segment
     __shared__ uint32_t scratch[NW + 1];
     const uint32_t h = blockIdx.x;
     if (h >= nheavy || nstretch[h] != 0) return;
@@ -198,19 +198,11 @@ __global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
     __syncthreads();
     for (uint64_t i = beg + threadIdx.x; i < end; i += kSplitThreads) atomicAdd(&segoff[stage[i].col >> sh], 1u);
     __syncthreads();
-    {   // exclusive scan of the segment counts (16 per thread), segment offsets out
-        constexpr int PER = (1 << kSplitMaxBits) / kSplitThreads;
-        uint32_t c[PER], sum = 0;
-#pragma unroll
-        for (int q = 0; q < PER; q++) { const uint32_t d = threadIdx.x * PER + q; c[q] = d < nseg ? segoff[d] : 0u; sum += c[q]; }
+    {   // exclusive scan of the segment counts -> segment offsets
+        const uint32_t c = threadIdx.x < nseg ? segoff[threadIdx.x] : 0u;
         uint32_t total;
-        uint32_t ex = block_excl_scan<uint32_t, kSplitThreads>(sum, scratch, &total);
-#pragma unroll
-        for (int q = 0; q < PER; q++) {
-            const uint32_t d = threadIdx.x * PER + q;
-            if (d < nseg) { segoff[d] = ex; vrow_off[vbase[h] + d] = qbase + ex; }
-            ex += c[q];
-        }
+        const uint32_t ex = block_excl_scan<uint32_t, kSplitThreads>(c, scratch, &total);
+        if (threadIdx.x < nseg) { segoff[threadIdx.x] = ex; vrow_off[vbase[h] + threadIdx.x] = qbase + ex; }
     }
     __syncthreads();
     for (uint64_t sb = beg; sb < end; sb += kSplitStretch) {
@@ -221,19 +213,18 @@ __global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
         }
         __syncthreads();  // also orders the segoff update of the previous round before this round's scatter
         const uint64_t wbeg = sb + (uint64_t)w * (kSplitStretch / NW);
-        uint32_t kc[ITERS], rk[ITERS];
-        T kv[ITERS];
+        uint32_t rk[ITERS];
+        PartWords<T> rec[ITERS];
 #pragma unroll
         for (int it = 0; it < ITERS; it++) {
             const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
-            kc[it] = 0; kv[it] = 0;
-            if (i < se) { const Part<T> pp = stage[i]; kc[it] = pp.col; kv[it] = pp.val; }
+            rec[it] = load_part_words(&stage[i < se ? i : sb]);  // branch-free: lanes past the end re-read the first record
         }
 #pragma unroll
         for (int it = 0; it < ITERS; it++) {
             const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
             const bool valid = i < se;
-            const unsigned d = kc[it] >> sh;
+            const unsigned d = rec[it].col() >> sh;
             unsigned r, c;
             wave_match_bits(d, (int)b, valid, r, c);
             rk[it] = 0;
@@ -256,8 +247,8 @@ __global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
         for (int it = 0; it < ITERS; it++) {
             const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
             if (i < se) {
-                const unsigned d = kc[it] >> sh;
-                qstage[qbase + segoff[d] + cnt[w][d] + rk[it]] = Part<T>{kc[it], kv[it]};
+                const unsigned d = rec[it].col() >> sh;
+                store_part_words(&qstage[qbase + segoff[d] + cnt[w][d] + rk[it]], rec[it]);
             }
         }
         __syncthreads();

@@ -1,6 +1,7 @@
 // tools/bench_merge.hip -- A/B timing of merge_tiles_kernel variants in ONE process (interleaved rounds).
 // Synthetic staging buffer: rows of `rowlen` partial products with random columns in [0, 2^22).
 // build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I outerspace_amd/csrc tools/bench_merge.hip -o tools/bench_merge
+#define OSP_MERGE_PROF 1
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -132,6 +133,7 @@ int main(int argc, char **argv) {
     std::vector<V> vs = {
         {"radix NT512 full", run<512, 0>}, {"radix NT512 nosort", run<512, 1>}, {"radix NT512 nolb", run<512, 2>},
         {"radix NT512 nosort+nolb", run<512, 3>}, {"runs NT1024 full", run_runs<1024, 0>},
+        {"radix NT1024 full", run<1024, 0>}, {"radix NT1024 nosort", run<1024, 1>},
     };
     if (getenv("CHECK_GRIDS")) {
         // the output must not depend on how many workgroups run or in which order they take tickets
@@ -150,6 +152,22 @@ int main(int argc, char **argv) {
                    (hs == ref && h_out[1] == ref_total) ? "same" : "DIFFERENT");
         }
         g_grid = 512;
+    }
+    if (getenv("PROF")) {
+        // where a workgroup's time goes: cycles between marks, summed over workgroups (thread 0's clock)
+        static const char *names[11] = {"wait for tile data", "stage + hash count", "publish", "pass: rank", "pass: digit scan",
+                                        "pass: scatter", "head flags + scan", "look-back + ticket", "run sums", "compact", "next request + output"};
+        unsigned long long z[16] = {0}, h[16];
+        for (int ab = 0; ab < 2; ab++) {
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(osp_merge_prof), z, sizeof(z)));
+            float ms = ab == 0 ? run<512, 0>(ARGS) : run<512, 2>(ARGS);
+            CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(osp_merge_prof), sizeof(h)));
+            unsigned long long tot = 0;
+            for (int k = 0; k < 11; k++) tot += h[k];
+            printf("%s: %.3f ms, %u tiles; cycles per tile per workgroup (share):\n", ab == 0 ? "full" : "no look-back", ms, ntiles);
+            for (int k = 0; k < 11; k++) printf("  %-24s %9.0f  %5.1f%%\n", names[k], (double)h[k] / ntiles, 100.0 * h[k] / tot);
+            printf("  %-24s %9.0f\n", "total", (double)tot / ntiles);
+        }
     }
     std::vector<std::vector<float>> t(vs.size());
     for (int round = 0; round < 5; round++)
