@@ -52,7 +52,7 @@ struct Context {
     std::multimap<size_t, void *> free_list;
     std::map<void *, size_t> live;
     size_t pooled_bytes = 0;
-    uint32_t merge_grid = 512;  // persistent workgroups of merge_tiles_kernel (2 per CU fit the LDS)
+    uint32_t cus = 256;  // persistent kernels size their grids from this
 
     static size_t bucket(size_t bytes) {
         if (bytes < 4096) return 4096;
@@ -342,7 +342,9 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
     OSP_HIP(hipMemsetAsync(tile_status, 0, (uint64_t)ntot * sizeof(uint64_t), s));
     OSP_HIP(hipMemsetAsync(ticket, 0, sizeof(uint32_t), s));
     tm.begin(PH_MERGE_K);
-    merge_tiles_kernel<T, kMergeThreads><<<std::min<uint32_t>(ntot, ctx->merge_grid), kMergeThreads, 0, s>>>(
+    // persistent workgroups: as many as the LDS lets run at once
+    const uint32_t merge_grid = ctx->cus * (uint32_t)((160 * 1024) / (sizeof(MergeSmem<T, kMergeThreads>) + 64));
+    merge_tiles_kernel<T, kMergeThreads><<<std::min<uint32_t>(ntot, merge_grid), kMergeThreads, 0, s>>>(
         desc, ntot, lv, colbits, tile_status, ticket, io.out_in, io.c_col, io.c_val, io.out_out);
     tm.end(PH_MERGE_K);
     res->info.merge_launches++;
@@ -862,7 +864,7 @@ static int context_create(int device, void *stream, bool own, osp_context_t *out
         throw Error(OSP_ERR_HIP, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     Context *c = new Context;
     c->device = device;
-    c->merge_grid = 2u * (uint32_t)prop.multiProcessorCount;
+    c->cus = (uint32_t)prop.multiProcessorCount;
     if (own) { OSP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     else c->stream = (hipStream_t)stream;
     *out = (osp_context_t)c;

@@ -17,12 +17,14 @@
 namespace osp {
 
 // ---- tunables --------------------------------------------------------------------------------
-// partial products one LDS merge tile holds: sized so that two workgroups fit the CU's 160 KiB LDS
+// partial products one LDS merge tile holds: sized so that FOUR workgroups of 256 threads fit the CU's 160 KiB
+// LDS.  (Measured, tools/bench_merge: four independent barrier domains per CU beat two workgroups of 512 threads
+// on tiles twice as large -- 3.5 vs 4.0 ms for 2.7e8 partial products -- although every tile costs a look-back.)
 template <class T> struct TileCap;
-template <> struct TileCap<float> { static constexpr int value = 3584; };
-template <> struct TileCap<double> { static constexpr int value = 3072; };
-constexpr int kTileMaxRows = 256;  // rows per tile (bounds the row bits of the sort key)
-constexpr int kMergeThreads = 512;
+template <> struct TileCap<float> { static constexpr int value = 1792; };
+template <> struct TileCap<double> { static constexpr int value = 1536; };
+constexpr int kMergeThreads = 256;
+constexpr int kTileMaxRows = kMergeThreads - 1;  // rows per tile: 8 row bits in the sort key, one row offset per thread
 constexpr int kMulThreads = 256;
 constexpr bool kMergeByRuns = false;  // see merge_pipeline() in osp_api.hip
 constexpr int kMulPerWave = 2048;  // partial products per wave slice
@@ -332,9 +334,9 @@ constexpr uint64_t kStatusAgg = 1ull << 62, kStatusPrefix = 2ull << 62, kStatusM
 constexpr int kDigitBits = 9;                 // radix of one LDS sort pass
 constexpr int kDigits = 1 << kDigitBits;      // 512 buckets
 
-template <class T, int NT>
+template <class T, int NT, int CAP = TileCap<T>::value>
 struct MergeSmem {
-    static constexpr int kTileCap = TileCap<T>::value;
+    static constexpr int kTileCap = CAP;
     uint32_t key[2][kTileCap];
     uint16_t pos[2][kTileCap];
     uint16_t rank[kTileCap + 1];
@@ -483,7 +485,7 @@ __global__ void chain_finish_kernel(const uint32_t *heavy_rows, uint32_t nlong, 
 // marks to osp_merge_prof[phase].  Compiled out of the library.
 #ifdef OSP_MERGE_PROF
 __device__ unsigned long long osp_merge_prof[16];
-#define OSP_PROF_DECL unsigned long long prof_acc[12] = {0}; unsigned long long prof_t = clock64();
+#define OSP_PROF_DECL __shared__ unsigned long long prof_acc[12]; if (tid < 12) prof_acc[tid] = 0; __syncthreads(); unsigned long long prof_t = clock64();
 #define OSP_PROF_MARK(k) do { if (tid == 0) { const unsigned long long now_ = clock64(); prof_acc[k] += now_ - prof_t; prof_t = now_; } } while (0)
 #define OSP_PROF_FLUSH do { if (tid == 0) for (int k_ = 0; k_ < 12; k_++) atomicAdd(&osp_merge_prof[k_], prof_acc[k_]); } while (0)
 #else
@@ -499,20 +501,27 @@ __device__ unsigned long long osp_merge_prof[16];
 // the descriptor of the NEXT tile are fetched by thread 0 while the current tile is being merged, and a
 // tile's row offsets and partial products are requested together, so one tile costs one exposed HBM
 // round trip instead of a chain of five.
-template <class T, int NT, int ABL = 0>
-__global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two workgroups per CU
+// workgroups of NT threads that fit one CU's 160 KiB of LDS -> waves per SIMD the register budget must allow
+template <class T, int NT, int CAP>
+constexpr int merge_waves_per_simd() {
+    const int wgs = (160 * 1024) / (int)(sizeof(MergeSmem<T, NT, CAP>) + 64);
+    const int w = wgs * NT / 256;
+    return w > 8 ? 8 : w;
+}
+template <class T, int NT, int ABL = 0, int CAP = TileCap<T>::value>
+__global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP>())) void merge_tiles_kernel(
     const TileDesc *__restrict__ desc, uint32_t ntiles, const MergeLevels<T> lvl, int colbits, uint64_t *tile_status,
     uint32_t *ticket, const uint64_t *__restrict__ out_base_p, uint32_t *__restrict__ c_col, T *__restrict__ c_val,
     uint64_t *__restrict__ out_end_p) {
-    __shared__ MergeSmem<T, NT> sm;
+    __shared__ MergeSmem<T, NT, CAP> sm;
     __shared__ TileDesc s_dnext;
     __shared__ uint32_t s_tnext;
-    constexpr int kTileCap = TileCap<T>::value;
+    constexpr int kTileCap = CAP;
     constexpr int NW = NT / kWave;
     constexpr int LPT = (kTileCap + NT - 1) / NT;
     constexpr int ITERS = (kTileCap / NW + kWave - 1) / kWave;  // wave iterations per sort pass
     constexpr int IPT = LPT;
-    static_assert(NT >= kDigits, "one thread per digit in the scan step");
+    constexpr int DPT = (kDigits + NT - 1) / NT;  // digits per thread in the scan step
     static_assert(kTileMaxRows + 1 <= NT, "row offsets are fetched one per thread");
     const unsigned tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     if (tid == 0) {
@@ -652,18 +661,24 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void merge_tiles_kernel(  // two 
             }
             __syncthreads();
             OSP_PROF_MARK(3);
-            // (b) exclusive scan over (digit major, wave minor); thread dg owns digit dg
+            // (b) exclusive scan over (digit major, wave minor); a thread owns DPT consecutive digits
             {
-                uint32_t c[NW], ssum = 0;
-                if (tid < kDigits) {
+                uint32_t c[DPT][NW], ssum = 0;
 #pragma unroll
-                    for (int ww = 0; ww < NW; ww++) { c[ww] = sm.cnt[ww][tid]; ssum += c[ww]; }
+                for (int q = 0; q < DPT; q++) {
+                    const int dg = tid * DPT + q;
+#pragma unroll
+                    for (int ww = 0; ww < NW; ww++) { c[q][ww] = dg < kDigits ? sm.cnt[ww][dg] : 0u; ssum += c[q][ww]; }
                 }
                 uint32_t total;
                 uint32_t ex = block_excl_scan<uint32_t, NT>(ssum, sm.scratch, &total);
-                if (tid < kDigits) {
 #pragma unroll
-                    for (int ww = 0; ww < NW; ww++) { sm.cnt[ww][tid] = (uint16_t)ex; ex += c[ww]; }
+                for (int q = 0; q < DPT; q++) {
+                    const int dg = tid * DPT + q;
+                    if (dg < kDigits) {
+#pragma unroll
+                        for (int ww = 0; ww < NW; ww++) { sm.cnt[ww][dg] = (uint16_t)ex; ex += c[q][ww]; }
+                    }
                 }
             }
             __syncthreads();

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 #include "osp_kernels.h"
@@ -70,7 +71,7 @@ __global__ void tiles_kernel(uint32_t *tile_rows, uint32_t ntiles, uint32_t rpt)
 }
 
 TileDesc *g_desc; uint32_t g_grid = 512;
-template <int NT, int ABL>
+template <int NT, int ABL, int CAP = 2 * NT * 3>
 float run(uint32_t *tile_rows, uint32_t ntiles, uint64_t M, uint64_t *row_off, uint32_t *pcol, double *pval,
           uint32_t *heavy, uint64_t *status, uint32_t *ticket, uint64_t *outn, int64_t *rowptr, uint32_t *ccol, double *cval) {
     hipEvent_t a, b;
@@ -81,7 +82,8 @@ float run(uint32_t *tile_rows, uint32_t ntiles, uint64_t M, uint64_t *row_off, u
     CK(hipEventRecord(a, 0));
     MergeLevels<double> lv{};
     lv.stage[0] = g_stage; lv.row_off[0] = row_off; lv.base[0] = 0; lv.c_rowptr[0] = rowptr; lv.heavy_nnz[0] = heavy;
-    merge_tiles_kernel<double, NT, ABL><<<ntiles < g_grid ? ntiles : g_grid, NT, 0, 0>>>(g_desc, ntiles, lv, 22, status, ticket, outn,
+    const uint32_t grid = g_grid * (uint32_t)((160 * 1024) / (sizeof(MergeSmem<double, NT, CAP>) + 64)) / 2;  // g_grid assumes 2 per CU
+    merge_tiles_kernel<double, NT, ABL, CAP><<<ntiles < grid ? ntiles : grid, NT, 0, 0>>>(g_desc, ntiles, lv, 22, status, ticket, outn,
                                                                                          ccol, cval, outn + 1);
     CK(hipEventRecord(b, 0));
     CK(hipEventSynchronize(b));
@@ -123,17 +125,19 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&g_stage, P * sizeof(Part<double>)));
     pack_kernel<<<(unsigned)((P + 255) / 256), 256>>>(pcol, pval, P, g_stage);
     CK(hipMalloc(&g_desc, (uint64_t)ntiles * sizeof(TileDesc)));
-    tile_desc_kernel<3072><<<(ntiles + 255) / 256, 256>>>(tile_rows, ntiles, M, row_off, 0, 0u, nullptr, nullptr, 0u, nullptr, g_desc);
+    tile_desc_kernel<1 << 20><<<(ntiles + 255) / 256, 256>>>(tile_rows, ntiles, M, row_off, 0, 0u, nullptr, nullptr, 0u, nullptr, g_desc);
     if (getenv("GRID")) g_grid = atoi(getenv("GRID"));
     CK(hipDeviceSynchronize());
     printf("P=%llu partials, %u tiles of %u rows x %u (%u per tile), algorithmic bytes %.2f GB\n", (unsigned long long)P, ntiles, rpt,
            rowlen, rpt * rowlen, (12.0 * P * 2) / 1e9);
 #define ARGS tile_rows, ntiles, M, row_off, pcol, pval, heavy, status, ticket, outn, rowptr, ccol, cval
-    struct V { const char *name; float (*fn)(uint32_t *, uint32_t, uint64_t, uint64_t *, uint32_t *, double *, uint32_t *, uint64_t *, uint32_t *, uint64_t *, int64_t *, uint32_t *, double *); };
+    struct V { const char *name; uint32_t cap; float (*fn)(uint32_t *, uint32_t, uint64_t, uint64_t *, uint32_t *, double *, uint32_t *, uint64_t *, uint32_t *, uint64_t *, int64_t *, uint32_t *, double *); };
     std::vector<V> vs = {
-        {"radix NT512 full", run<512, 0>}, {"radix NT512 nosort", run<512, 1>}, {"radix NT512 nolb", run<512, 2>},
-        {"radix NT512 nosort+nolb", run<512, 3>}, {"runs NT1024 full", run_runs<1024, 0>},
-        {"radix NT1024 full", run<1024, 0>}, {"radix NT1024 nosort", run<1024, 1>},
+        {"radix NT256 cap1536 full", 1536, run<256, 0, 1536>}, {"radix NT256 cap1536 nosort", 1536, run<256, 1, 1536>},
+        {"radix NT256 cap1536 nolb", 1536, run<256, 2, 1536>}, {"radix NT256 cap1536 nosort+nolb", 1536, run<256, 3, 1536>},
+        {"radix NT512 cap3072 full", 3072, run<512, 0, 3072>}, {"radix NT512 cap2048 full", 2048, run<512, 0, 2048>},
+        {"radix NT256 cap2048 full", 2048, run<256, 0, 2048>}, {"radix NT256 cap1280 full", 1280, run<256, 0, 1280>},
+        {"runs NT1024 full", 3072, run_runs<1024, 0>},
     };
     if (getenv("CHECK_GRIDS")) {
         // the output must not depend on how many workgroups run or in which order they take tickets
@@ -141,7 +145,7 @@ int main(int argc, char **argv) {
         unsigned long long ref = 0; uint64_t ref_total = 0;
         for (uint32_t g : {512u, 1u, 7u, 64u, 511u, 513u, 1000u, 4096u, 100000u}) {
             g_grid = g;
-            float ms = run<512, 0>(ARGS);
+            float ms = run<256, 0, 1536>(ARGS);
             uint64_t h_out[2]; CK(hipMemcpy(h_out, outn, 16, hipMemcpyDeviceToHost));
             CK(hipMemset(d_sum, 0, 8));
             const uint64_t n = std::max<uint64_t>(M + 1, h_out[1]);
@@ -160,7 +164,7 @@ int main(int argc, char **argv) {
         unsigned long long z[16] = {0}, h[16];
         for (int ab = 0; ab < 2; ab++) {
             CK(hipMemcpyToSymbol(HIP_SYMBOL(osp_merge_prof), z, sizeof(z)));
-            float ms = ab == 0 ? run<512, 0>(ARGS) : run<512, 2>(ARGS);
+            float ms = ab == 0 ? run<256, 0, 1536>(ARGS) : run<256, 2, 1536>(ARGS);
             CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(osp_merge_prof), sizeof(h)));
             unsigned long long tot = 0;
             for (int k = 0; k < 11; k++) tot += h[k];
@@ -169,9 +173,22 @@ int main(int argc, char **argv) {
             printf("  %-24s %9.0f\n", "total", (double)tot / ntiles);
         }
     }
+    {   // variants whose tile capacity is below this run's tile size do not apply
+        std::vector<V> keep;
+        for (auto &v : vs) if (v.cap >= rpt * rowlen) keep.push_back(v);
+        vs = keep;
+    }
+    if (getenv("ONLY")) {  // run one variant alone (substring match), announcing it first
+        std::vector<V> keep;
+        for (auto &v : vs) if (strstr(v.name, getenv("ONLY"))) keep.push_back(v);
+        vs = keep;
+    }
     std::vector<std::vector<float>> t(vs.size());
     for (int round = 0; round < 5; round++)
-        for (size_t v = 0; v < vs.size(); v++) t[v].push_back(vs[v].fn(ARGS));
+        for (size_t v = 0; v < vs.size(); v++) {
+            if (getenv("ONLY")) { printf("round %d: %s\n", round, vs[v].name); fflush(stdout); }
+            t[v].push_back(vs[v].fn(ARGS));
+        }
     for (size_t v = 0; v < vs.size(); v++) {
         std::sort(t[v].begin(), t[v].end());
         printf("%-28s median %8.3f ms  min %8.3f ms   %7.1f GB/s (alg)\n", vs[v].name, t[v][2], t[v][0], 24.0 * P / (t[v][2] * 1e-3) / 1e9);
