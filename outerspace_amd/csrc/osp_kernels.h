@@ -494,7 +494,8 @@ __device__ unsigned long long osp_merge_prof[16];
 #define OSP_PROF_FLUSH
 #endif
 
-// ABL: ablation switches for tools/bench_merge.hip only (1 = no sort, 2 = no look-back, 4 = no ticket);
+// ABL: ablation switches for tools/bench_merge.hip only (1 = no sort, 2 = no look-back, 4 = no ticket,
+// 8 = entry count published after the sort instead of by hashing);
 // the library always instantiates ABL = 0.
 //
 // Persistent workgroups: each takes tiles from the ticket counter until none are left.  The ticket and
@@ -594,7 +595,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP>())) void merg
         // the first sort pass (key[1], pos[], rank[]: exactly 2.5 words per entry).
         constexpr uint32_t HS = (uint32_t)kTileCap * 5u / 2u;
         uint32_t *htab = &sm.key[1][0];
-        const bool early = nbits > 0 && colbits + rowbits < 32 && !(ABL & 2);
+        const bool early = nbits > 0 && colbits + rowbits < 32 && !(ABL & 2) && !(ABL & 8);
         if (early) {
             for (uint32_t i = tid; i < HS; i += NT) htab[i] = 0xffffffffu;
             if (tid == 0) sm.hcount = 0;
@@ -604,23 +605,37 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP>())) void merg
         OSP_PROF_MARK(0);
         // stage: key = (local row << colbits) | col; the payload (staging position) is implicit until pass 0
         uint32_t fresh = 0;
+        uint32_t kq[LPT];
 #pragma unroll
         for (int q = 0; q < LPT; q++) {
             const uint32_t i = tid + q * NT;
+            kq[q] = 0;
             if (i < n) {
                 uint32_t lo = 0, hi = nr;  // last r with rowo[r] <= i
                 while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sm.rowo[mid] <= i) lo = mid; else hi = mid; }
-                const uint32_t k = (colbits < 32 ? (lo << colbits) : 0u) | lrec[q].col();
-                sm.key[0][i] = k;
+                kq[q] = (colbits < 32 ? (lo << colbits) : 0u) | lrec[q].col();
+                sm.key[0][i] = kq[q];
                 sm.val[i] = lrec[q].val();
-                if (early) {
-                    uint32_t h = (uint32_t)(((uint64_t)(k * 2654435761u) * HS) >> 32);
-                    while (true) {
-                        const uint32_t old = atomicCAS(&htab[h], 0xffffffffu, k);
-                        if (old == 0xffffffffu) { fresh++; break; }
-                        if (old == k) break;
+            }
+        }
+        if (early) {
+            // first probes of all the thread's keys go out together; only collisions with a different key walk on
+            uint32_t hq[LPT], oq[LPT];
+#pragma unroll
+            for (int q = 0; q < LPT; q++) {
+                hq[q] = (uint32_t)(((uint64_t)(kq[q] * 2654435761u) * HS) >> 32);
+                oq[q] = kq[q];
+                if (tid + q * NT < n) oq[q] = atomicCAS(&htab[hq[q]], 0xffffffffu, kq[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < LPT; q++) {
+                if (tid + q * NT < n) {
+                    uint32_t old = oq[q], h = hq[q];
+                    while (old != 0xffffffffu && old != kq[q]) {
                         h = (h + 1 == HS) ? 0u : h + 1;
+                        old = atomicCAS(&htab[h], 0xffffffffu, kq[q]);
                     }
+                    fresh += old == 0xffffffffu;
                 }
             }
         }

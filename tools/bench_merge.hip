@@ -135,6 +135,7 @@ int main(int argc, char **argv) {
     std::vector<V> vs = {
         {"radix NT256 cap1536 full", 1536, run<256, 0, 1536>}, {"radix NT256 cap1536 nosort", 1536, run<256, 1, 1536>},
         {"radix NT256 cap1536 nolb", 1536, run<256, 2, 1536>}, {"radix NT256 cap1536 nosort+nolb", 1536, run<256, 3, 1536>},
+        {"radix NT256 cap1536 latecount", 1536, run<256, 8, 1536>},
         {"radix NT512 cap3072 full", 3072, run<512, 0, 3072>}, {"radix NT512 cap2048 full", 2048, run<512, 0, 2048>},
         {"radix NT256 cap2048 full", 2048, run<256, 0, 2048>}, {"radix NT256 cap1280 full", 1280, run<256, 0, 1280>},
         {"runs NT1024 full", 3072, run_runs<1024, 0>},
