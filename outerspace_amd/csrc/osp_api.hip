@@ -327,15 +327,15 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
                                                                   p1.ntiles, j0, tb, extra);
         device_exclusive_scan<LoadU32, uint32_t>(LoadU32{extra}, nlong, extra, (uint32_t *)hscan_tmp, s);
         ntot = p0.ntiles + d2h(extra + nlong, s);
-        desc = (TileDesc *)sc.get<uint64_t>((uint64_t)ntot * 3);
+        desc = sc.get<TileDesc>(ntot);
         tile_desc_kernel<(int)kCap><<<grid_for(p0.ntiles, 256), 256, 0, s>>>(p0.tile_rows, p0.ntiles, r1, io.row_off, base, 0u, j0, extra,
-                                                                           nlong, tb, desc);
+                                                                           nlong, tb, colbits, hbits, vbase, desc);
         tile_desc_kernel<(int)kCap><<<grid_for(p1.ntiles, 256), 256, 0, s>>>(p1.tile_rows, p1.ntiles, nvirt, vrow_off, 0, 1u, j0, extra,
-                                                                           nlong, tb, desc);
+                                                                           nlong, tb, colbits, hbits, vbase, desc);
     } else {
-        desc = (TileDesc *)sc.get<uint64_t>((uint64_t)ntot * 3);
+        desc = sc.get<TileDesc>(ntot);
         tile_desc_kernel<(int)kCap><<<grid_for(p0.ntiles, 256), 256, 0, s>>>(p0.tile_rows, p0.ntiles, r1, io.row_off, base, 0u, nullptr,
-                                                                           nullptr, 0u, nullptr, desc);
+                                                                           nullptr, 0u, nullptr, colbits, nullptr, nullptr, desc);
     }
     uint64_t *tile_status = sc.get<uint64_t>(ntot);
     uint32_t *ticket = sc.get<uint32_t>(1);
@@ -343,7 +343,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
     OSP_HIP(hipMemsetAsync(ticket, 0, sizeof(uint32_t), s));
     tm.begin(PH_MERGE_K);
     // persistent workgroups: as many as the LDS lets run at once
-    const uint32_t merge_grid = ctx->cus * (uint32_t)((160 * 1024) / (sizeof(MergeSmem<T, kMergeThreads>) + 64));
+    const uint32_t merge_grid = ctx->cus * (uint32_t)merge_wgs_per_cu<T, kMergeThreads, TileCap<T>::value>();
     merge_tiles_kernel<T, kMergeThreads><<<std::min<uint32_t>(ntot, merge_grid), kMergeThreads, 0, s>>>(
         desc, ntot, lv, colbits, tile_status, ticket, io.out_in, io.c_col, io.c_val, io.out_out);
     tm.end(PH_MERGE_K);

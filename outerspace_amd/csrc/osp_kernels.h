@@ -12,6 +12,7 @@
 //              Rows too long for LDS take the global-sort path.
 //   compact    per-row results -> final CSR at exact offsets.
 #pragma once
+#include <type_traits>
 #include "osp_prims.h"
 
 namespace osp {
@@ -331,31 +332,53 @@ __global__ void compact_flagged_kernel(F f, const uint32_t *scan, uint64_t n, ui
 // rows are written ONCE, straight to c_col / c_val / c_rowptr (no per-row compaction pass).
 constexpr uint64_t kStatusAgg = 1ull << 62, kStatusPrefix = 2ull << 62, kStatusMask = (1ull << 62) - 1;
 
-constexpr int kDigitBits = 9;                 // radix of one LDS sort pass
-constexpr int kDigits = 1 << kDigitBits;      // 512 buckets
+#ifndef OSP_DIGIT_BITS
+#define OSP_DIGIT_BITS 10
+#endif
+constexpr int kDigitBits = OSP_DIGIT_BITS;    // widest radix of one LDS sort pass: 20 key bits sort in two passes
+constexpr int kDigits = 1 << kDigitBits;      // 1024 buckets
 
+// LDS of one merge workgroup: 14 bytes per tile entry + the digit counters.
+//   key0 | pos0 | pad | key1 | pos1     two (key, staging position) buffers the sort passes ping-pong between
+// The values never take part in the sort: they wait in registers and are written, after the last pass, into
+// the 8 bytes per entry that do not hold the sorted keys -- (key0, pos0, pad) when the sorted keys sit in
+// buffer 1, (pad, key1, pos1) when they sit in buffer 0; that is what `pad` is for.  Before the first pass the
+// hash set that counts the tile's distinct keys uses everything behind key0 (10 bytes = 2.5 words per entry).
+// After the last pass the digit counters are dead and hold `rank` (output slot per sorted position).
 template <class T, int NT, int CAP = TileCap<T>::value>
-struct MergeSmem {
+struct alignas(8) MergeSmem {
     static constexpr int kTileCap = CAP;
-    uint32_t key[2][kTileCap];
-    uint16_t pos[2][kTileCap];
-    uint16_t rank[kTileCap + 1];
-    T val[kTileCap];
-    uint16_t cnt[NT / kWave][kDigits];
+    static_assert(CAP % 4 == 0, "the value area behind key0/pos0 must stay 8-byte aligned");
+    static_assert(sizeof(T) <= 8, "values alias 8 bytes per entry");
+    uint32_t key0[CAP];
+    uint16_t pos0[CAP];
+    uint16_t pad[CAP];
+    uint32_t key1[CAP];
+    uint16_t pos1[CAP];
+    union {
+        uint16_t cnt[NT / kWave][kDigits];
+        uint16_t rank[CAP + 1];
+    };
     uint32_t rowo[kTileMaxRows + 1];
     uint32_t scratch[NT / kWave + 1];
     uint32_t tile;
     uint32_t hcount;  // distinct (row, col) keys of the tile, counted by hashing before the sort
     uint64_t excl;
+    __device__ __forceinline__ uint32_t *key(int c) { return c ? key1 : key0; }
+    __device__ __forceinline__ uint16_t *pos(int c) { return c ? pos1 : pos0; }
+    // where the values go once the sorted keys sit in buffer `c`
+    __device__ __forceinline__ T *vals(int c) { return reinterpret_cast<T *>(c ? reinterpret_cast<char *>(key0) : reinterpret_cast<char *>(pad)); }
+    __device__ __forceinline__ uint32_t *htab() { return reinterpret_cast<uint32_t *>(pos0); }
 };
 
 // Rank of this lane among the lanes of its wave that hold the same digit (lower lanes first), and
-// the size of that group.  kDigitBits ballots; per bit one sign mask, one xnor and one and per half.
+// the size of that group.  BITS ballots; per bit one sign mask, one xnor and one and per half.
+template <int BITS>
 __device__ __forceinline__ void wave_match_digit(unsigned digit, bool valid, unsigned &rank, unsigned &count) {
     const uint64_t vm = __ballot(valid);
     uint32_t plo = (uint32_t)vm, phi = (uint32_t)(vm >> 32);
 #pragma unroll
-    for (int b = 0; b < kDigitBits; b++) {
+    for (int b = 0; b < BITS; b++) {
         const uint32_t bit = (digit >> b) & 1u;
         const uint64_t m = __ballot(bit != 0);
         const uint32_t sbm = 0u - bit;  // all ones where my bit is set
@@ -422,6 +445,10 @@ __device__ __forceinline__ uint64_t lookback_prefix(uint64_t *status, uint32_t t
 struct TileDesc {
     uint64_t s;
     uint32_t ra, nr, n, lvl;
+    // sort key of a level-1 tile: its segments are consecutive column ranges of ONE long row, so the column
+    // itself orders them; key = col - cbase needs kbits bits (about log2(N * tile / row length), often <= 20:
+    // two sort passes).  kbits = 0: level-0 key (local row, col).
+    uint32_t cbase, kbits;
 };
 // Everything merge_tiles_kernel needs per level.
 template <class T>
@@ -437,7 +464,7 @@ struct MergeLevels {
 template <int CAP>
 __global__ void tile_desc_kernel(const uint32_t *tile_rows, uint32_t ntiles, uint64_t r_end, const uint64_t *row_off,
                                  uint64_t base, uint32_t lvl, const uint32_t *j0, const uint32_t *extra, uint32_t nlong,
-                                 const uint32_t *tb, TileDesc *desc) {
+                                 const uint32_t *tb, int colbits, const uint8_t *hbits, const uint64_t *vbase, TileDesc *desc) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
     const uint64_t ra = tile_rows[t], rb = (t + 1 < ntiles) ? (uint64_t)tile_rows[t + 1] : r_end;
@@ -447,6 +474,8 @@ __global__ void tile_desc_kernel(const uint32_t *tile_rows, uint32_t ntiles, uin
     d.nr = (uint32_t)(rb - ra);
     d.n = (uint32_t)min(row_off[rb] - base - d.s, (uint64_t)CAP + 1);  // CAP+1 = "a single long row"
     d.lvl = lvl;
+    d.cbase = 0;
+    d.kbits = 0;
     uint32_t pos = t;
     if (nlong) {
         if (lvl == 0) {
@@ -456,6 +485,12 @@ __global__ void tile_desc_kernel(const uint32_t *tile_rows, uint32_t ntiles, uin
         } else {
             const uint32_t h = (uint32_t)(upper_bound_dev(tb, 0, (uint64_t)nlong + 1, t) - 1);  // owner long row
             pos = j0[h] + extra[h] + (t - tb[h]);
+            const int sh = colbits - (int)hbits[h];              // log2 of a segment's column range
+            d.cbase = (uint32_t)((ra - vbase[h]) << sh);
+            const uint64_t range = (uint64_t)d.nr << sh;
+            int kb = 1;
+            while (kb < 32 && (1ull << kb) < range) kb++;
+            d.kbits = (uint32_t)kb;
         }
     }
     desc[pos] = d;
@@ -503,14 +538,19 @@ __device__ unsigned long long osp_merge_prof[16];
 // tile's row offsets and partial products are requested together, so one tile costs one exposed HBM
 // round trip instead of a chain of five.
 // workgroups of NT threads that fit one CU's 160 KiB of LDS -> waves per SIMD the register budget must allow
-template <class T, int NT, int CAP>
-constexpr int merge_waves_per_simd() {
+constexpr int kMergeMaxWgs = 5;  // per CU (measured: five workgroups at <= 102 registers, a few spilled, beat four at 120)
+template <class T, int NT, int CAP, int MAXWG = kMergeMaxWgs>
+constexpr int merge_wgs_per_cu() {
     const int wgs = (160 * 1024) / (int)(sizeof(MergeSmem<T, NT, CAP>) + 64);
-    const int w = wgs * NT / 256;
-    return w > 8 ? 8 : w;
+    return wgs > MAXWG ? MAXWG : wgs;
 }
-template <class T, int NT, int ABL = 0, int CAP = TileCap<T>::value>
-__global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP>())) void merge_tiles_kernel(
+template <class T, int NT, int CAP, int MAXWG = kMergeMaxWgs>
+constexpr int merge_waves_per_simd() {
+    const int w = merge_wgs_per_cu<T, NT, CAP, MAXWG>() * NT / 256;
+    return w > 8 ? 8 : (w < 1 ? 1 : w);
+}
+template <class T, int NT, int ABL = 0, int CAP = TileCap<T>::value, int MAXWG = kMergeMaxWgs>
+__global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG>())) void merge_tiles_kernel(
     const TileDesc *__restrict__ desc, uint32_t ntiles, const MergeLevels<T> lvl, int colbits, uint64_t *tile_status,
     uint32_t *ticket, const uint64_t *__restrict__ out_base_p, uint32_t *__restrict__ c_col, T *__restrict__ c_val,
     uint64_t *__restrict__ out_end_p) {
@@ -588,14 +628,17 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP>())) void merg
         }
         int rowbits = 0;
         while ((1u << rowbits) < nr) rowbits++;
-        const int nbits = (n && !(ABL & 1)) ? colbits + rowbits : 0;
+        const bool relkey = d.kbits != 0;  // level-1 tile: key = col - cbase
+        const uint32_t cbase = d.cbase;
+        const int keybits = relkey ? (int)d.kbits : colbits + rowbits;
+        const int nbits = (n && !(ABL & 1)) ? keybits : 0;
         // The tile's entry count (= distinct keys) is needed by every later tile's look-back.  Waiting for
-        // the sort to deliver it makes successors stall behind slower predecessors; a hash set over the keys
-        // gives the same number right after staging, ~10 us earlier.  The table lives in LDS that is idle until
-        // the first sort pass (key[1], pos[], rank[]: exactly 2.5 words per entry).
+        // the sort to deliver it makes successors stall behind slower predecessors (measured: +27 %); a hash set
+        // over the keys gives the same number right after staging.  The table lives in LDS that is idle until the
+        // first sort pass (everything behind key0: exactly 2.5 words per entry).
         constexpr uint32_t HS = (uint32_t)kTileCap * 5u / 2u;
-        uint32_t *htab = &sm.key[1][0];
-        const bool early = nbits > 0 && colbits + rowbits < 32 && !(ABL & 2) && !(ABL & 8);
+        uint32_t *htab = sm.htab();
+        const bool early = nbits > 0 && keybits < 32 && !(ABL & 2) && !(ABL & 8);
         if (early) {
             for (uint32_t i = tid; i < HS; i += NT) htab[i] = 0xffffffffu;
             if (tid == 0) sm.hcount = 0;
@@ -603,7 +646,8 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP>())) void merg
         if (tid <= nr) sm.rowo[tid] = (uint32_t)(ro - base - s);
         __syncthreads();
         OSP_PROF_MARK(0);
-        // stage: key = (local row << colbits) | col; the payload (staging position) is implicit until pass 0
+        // stage the keys: (local row << colbits) | col, or col - cbase.  The payload (staging position) is implicit
+        // until pass 0; the values stay in registers until the sort is over.
         uint32_t fresh = 0;
         uint32_t kq[LPT];
 #pragma unroll
@@ -611,11 +655,14 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP>())) void merg
             const uint32_t i = tid + q * NT;
             kq[q] = 0;
             if (i < n) {
-                uint32_t lo = 0, hi = nr;  // last r with rowo[r] <= i
-                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sm.rowo[mid] <= i) lo = mid; else hi = mid; }
-                kq[q] = (colbits < 32 ? (lo << colbits) : 0u) | lrec[q].col();
-                sm.key[0][i] = kq[q];
-                sm.val[i] = lrec[q].val();
+                if (relkey) {
+                    kq[q] = lrec[q].col() - cbase;
+                } else {
+                    uint32_t lo = 0, hi = nr;  // last r with rowo[r] <= i
+                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sm.rowo[mid] <= i) lo = mid; else hi = mid; }
+                    kq[q] = (colbits < 32 ? (lo << colbits) : 0u) | lrec[q].col();
+                }
+                sm.key0[i] = kq[q];
             }
         }
         if (early) {
@@ -638,8 +685,6 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP>())) void merg
                     fresh += old == 0xffffffffu;
                 }
             }
-        }
-        if (early) {
             const uint32_t wsum = wave_reduce_sum(fresh);
             if (lane == 0 && wsum) atomicAdd(&sm.hcount, wsum);
             __syncthreads();
@@ -655,42 +700,53 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP>())) void merg
         const int npass = (nbits + kDigitBits - 1) / kDigitBits;
         const int pbits = npass ? (nbits + npass - 1) / npass : 0;  // balanced digit width (<= kDigitBits)
         const uint32_t dmask = (1u << pbits) - 1u;
+        const int ndig = 1 << pbits;                                // digits in use: counters beyond are not touched
         for (int pass = 0, shift = 0; pass < npass; pass++, shift += pbits) {
-            for (int dd = lane; dd < kDigits; dd += kWave) sm.cnt[w][dd] = 0;
+            uint32_t *ksrc = sm.key(cur), *kdst = sm.key(cur ^ 1);
+            uint16_t *psrc = sm.pos(cur), *pdst = sm.pos(cur ^ 1);
+            for (int dd = lane; dd < ndig; dd += kWave) sm.cnt[w][dd] = 0;
             // (a) rank inside the wave's span; keys and ranks stay in registers for (c)
             uint32_t kreg[ITERS], rreg[ITERS];
+            auto rank_span = [&](auto bits_tag) {
+                constexpr int BITS = decltype(bits_tag)::value;
 #pragma unroll
-            for (int it = 0; it < ITERS; it++) {
-                const uint32_t i = wbeg + it * kWave + lane;
-                const bool valid = i < wend;
-                kreg[it] = valid ? sm.key[cur][i] : 0u;
-                const unsigned dg = (kreg[it] >> shift) & dmask;
-                unsigned rk, cntd;
-                wave_match_digit(dg, valid, rk, cntd);
-                rreg[it] = 0;
-                if (valid) {
-                    const uint32_t c = sm.cnt[w][dg];
-                    rreg[it] = c + rk;
-                    if (rk == 0) sm.cnt[w][dg] = (uint16_t)(c + cntd);
+                for (int it = 0; it < ITERS; it++) {
+                    const uint32_t i = wbeg + it * kWave + lane;
+                    const bool valid = i < wend;
+                    kreg[it] = valid ? ksrc[i] : 0u;
+                    const unsigned dg = (kreg[it] >> shift) & dmask;
+                    unsigned rk, cntd;
+                    wave_match_digit<BITS>(dg, valid, rk, cntd);
+                    rreg[it] = 0;
+                    if (valid) {
+                        const uint32_t c = sm.cnt[w][dg];
+                        rreg[it] = c + rk;
+                        if (rk == 0) sm.cnt[w][dg] = (uint16_t)(c + cntd);
+                    }
                 }
-            }
+            };
+            // the widest digits only when they save a pass (20 key bits in two passes); else one ballot less
+            if (pbits > kDigitBits - 1) rank_span(std::integral_constant<int, kDigitBits>{});
+            else rank_span(std::integral_constant<int, kDigitBits - 1>{});
             __syncthreads();
             OSP_PROF_MARK(3);
-            // (b) exclusive scan over (digit major, wave minor); a thread owns DPT consecutive digits
+            // (b) exclusive scan over (digit major, wave minor); a thread owns dpt consecutive digits
             {
+                const int dpt = ndig > NT ? ndig / NT : 1;  // ndig and NT are powers of two
                 uint32_t c[DPT][NW], ssum = 0;
 #pragma unroll
                 for (int q = 0; q < DPT; q++) {
-                    const int dg = tid * DPT + q;
+                    const int dg = tid * dpt + q;
+                    const bool on = q < dpt && dg < ndig;
 #pragma unroll
-                    for (int ww = 0; ww < NW; ww++) { c[q][ww] = dg < kDigits ? sm.cnt[ww][dg] : 0u; ssum += c[q][ww]; }
+                    for (int ww = 0; ww < NW; ww++) { c[q][ww] = on ? sm.cnt[ww][dg] : 0u; ssum += c[q][ww]; }
                 }
                 uint32_t total;
                 uint32_t ex = block_excl_scan<uint32_t, NT>(ssum, sm.scratch, &total);
 #pragma unroll
                 for (int q = 0; q < DPT; q++) {
-                    const int dg = tid * DPT + q;
-                    if (dg < kDigits) {
+                    const int dg = tid * dpt + q;
+                    if (q < dpt && dg < ndig) {
 #pragma unroll
                         for (int ww = 0; ww < NW; ww++) { sm.cnt[ww][dg] = (uint16_t)ex; ex += c[q][ww]; }
                     }
@@ -705,18 +761,27 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP>())) void merg
                 if (i < wend) {
                     const uint32_t k = kreg[it];
                     const uint32_t dst = (uint32_t)sm.cnt[w][(k >> shift) & dmask] + rreg[it];
-                    sm.key[cur ^ 1][dst] = k;
-                    sm.pos[cur ^ 1][dst] = pass == 0 ? (uint16_t)i : sm.pos[cur][i];
+                    kdst[dst] = k;
+                    pdst[dst] = pass == 0 ? (uint16_t)i : psrc[i];
                 }
             }
             cur ^= 1;
             __syncthreads();
             OSP_PROF_MARK(5);
         }
+        uint32_t *skey = sm.key(cur);   // sorted keys and their staging positions
+        uint16_t *spos = sm.pos(cur);
+        T *sval = sm.vals(cur);         // the 8 bytes per entry beside them: values by staging position
         if (npass == 0) {  // nothing was sorted (empty tile): the payload is still implicit
-            for (uint32_t i = tid; i < n; i += NT) sm.pos[0][i] = (uint16_t)i;
-            __syncthreads();
+            for (uint32_t i = tid; i < n; i += NT) spos[i] = (uint16_t)i;
         }
+        // the values leave the registers now; the barriers inside the scan below order this before the run sums
+#pragma unroll
+        for (int q = 0; q < LPT; q++) {
+            const uint32_t i = tid + q * NT;
+            if (i < n) sval[i] = lrec[q].val();
+        }
+        if (npass == 0) __syncthreads();
         // head flags + exclusive scan (blocked: thread owns IPT consecutive sorted entries)
         const uint32_t ib = tid * IPT;
         uint32_t heads = 0, hmask = 0;
@@ -724,7 +789,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP>())) void merg
         for (int q = 0; q < IPT; q++) {
             const uint32_t i = ib + q;
             if (i < n) {
-                const bool h = (i == 0) || (sm.key[cur][i] != sm.key[cur][i - 1]);
+                const bool h = (i == 0) || (skey[i] != skey[i - 1]);
                 hmask |= (h ? 1u : 0u) << q;
                 heads += h;
             }
@@ -750,7 +815,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP>())) void merg
             const uint32_t i = ib + q;
             oslot[q] = ex;
             if (i < n) {
-                sm.rank[i] = (uint16_t)ex;  // output slot of the run that starts at/behind i
+                sm.rank[i] = (uint16_t)ex;  // output slot of the run that starts at/behind i (the counters are dead)
                 ex += (hmask >> q) & 1u;
             }
         }
@@ -763,22 +828,22 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP>())) void merg
             const uint32_t i = ib + q;
             acc[q] = 0; ocol[q] = 0;
             if (i < n && ((hmask >> q) & 1u)) {
-                const uint32_t k = sm.key[cur][i];
-                T a = sm.val[sm.pos[cur][i]];
-                for (uint32_t u = i + 1; u < n && sm.key[cur][u] == k; u++) a += sm.val[sm.pos[cur][u]];
+                const uint32_t k = skey[i];
+                T a = sval[spos[i]];
+                for (uint32_t u = i + 1; u < n && skey[u] == k; u++) a += sval[spos[u]];
                 acc[q] = a;
-                ocol[q] = k & colmask;
+                ocol[q] = relkey ? k + cbase : (k & colmask);
             }
         }
         if (tid == 0) s_tnext = tn_reg;
-        __syncthreads();  // all gathers from val[] / key[cur] done; sm.excl and s_tnext are published
+        __syncthreads();  // all gathers from the keys / values done; sm.excl and s_tnext are published
         OSP_PROF_MARK(8);
-        // compact into LDS (val[] and the idle key buffer), then stream out with consecutive lanes on
-        // consecutive addresses
+        // compact in LDS (columns over the sorted keys, sums over the values), then stream out with consecutive
+        // lanes on consecutive addresses
 #pragma unroll
         for (int q = 0; q < IPT; q++) {
             const uint32_t i = ib + q;
-            if (i < n && ((hmask >> q) & 1u)) { sm.key[cur ^ 1][oslot[q]] = ocol[q]; sm.val[oslot[q]] = acc[q]; }
+            if (i < n && ((hmask >> q) & 1u)) { skey[oslot[q]] = ocol[q]; sval[oslot[q]] = acc[q]; }
         }
         if (tid == 0 && tn_reg < ntiles) s_dnext = desc[tn_reg];
         __syncthreads();
@@ -788,7 +853,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP>())) void merg
         // the next tile's HBM reads go out ahead of this tile's writes
         request(dn, tn < ntiles);
         const uint64_t obase = out_base + sm.excl;
-        for (uint32_t o = tid; o < total; o += NT) { c_col[obase + o] = sm.key[cur ^ 1][o]; c_val[obase + o] = sm.val[o]; }
+        for (uint32_t o = tid; o < total; o += NT) { c_col[obase + o] = skey[o]; c_val[obase + o] = sval[o]; }
         // rows keep their index span through the sort (row is the major key)
         if (tid < nr) c_rowptr[ra + tid] = (int64_t)(obase + sm.rank[sm.rowo[tid]]);
         if (t + 1 == ntiles && tid == 0) *out_end_p = obase + total;

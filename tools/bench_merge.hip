@@ -71,7 +71,7 @@ __global__ void tiles_kernel(uint32_t *tile_rows, uint32_t ntiles, uint32_t rpt)
 }
 
 TileDesc *g_desc; uint32_t g_grid = 512;
-template <int NT, int ABL, int CAP = 2 * NT * 3>
+template <int NT, int ABL, int CAP = 2 * NT * 3, int MAXWG = 5>
 float run(uint32_t *tile_rows, uint32_t ntiles, uint64_t M, uint64_t *row_off, uint32_t *pcol, double *pval,
           uint32_t *heavy, uint64_t *status, uint32_t *ticket, uint64_t *outn, int64_t *rowptr, uint32_t *ccol, double *cval) {
     hipEvent_t a, b;
@@ -82,8 +82,8 @@ float run(uint32_t *tile_rows, uint32_t ntiles, uint64_t M, uint64_t *row_off, u
     CK(hipEventRecord(a, 0));
     MergeLevels<double> lv{};
     lv.stage[0] = g_stage; lv.row_off[0] = row_off; lv.base[0] = 0; lv.c_rowptr[0] = rowptr; lv.heavy_nnz[0] = heavy;
-    const uint32_t grid = g_grid * (uint32_t)((160 * 1024) / (sizeof(MergeSmem<double, NT, CAP>) + 64)) / 2;  // g_grid assumes 2 per CU
-    merge_tiles_kernel<double, NT, ABL, CAP><<<ntiles < grid ? ntiles : grid, NT, 0, 0>>>(g_desc, ntiles, lv, 22, status, ticket, outn,
+    const uint32_t grid = g_grid * (uint32_t)merge_wgs_per_cu<double, NT, CAP, MAXWG>() / 2;  // g_grid assumes 2 per CU
+    merge_tiles_kernel<double, NT, ABL, CAP, MAXWG><<<ntiles < grid ? ntiles : grid, NT, 0, 0>>>(g_desc, ntiles, lv, 22, status, ticket, outn,
                                                                                          ccol, cval, outn + 1);
     CK(hipEventRecord(b, 0));
     CK(hipEventSynchronize(b));
@@ -125,7 +125,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&g_stage, P * sizeof(Part<double>)));
     pack_kernel<<<(unsigned)((P + 255) / 256), 256>>>(pcol, pval, P, g_stage);
     CK(hipMalloc(&g_desc, (uint64_t)ntiles * sizeof(TileDesc)));
-    tile_desc_kernel<1 << 20><<<(ntiles + 255) / 256, 256>>>(tile_rows, ntiles, M, row_off, 0, 0u, nullptr, nullptr, 0u, nullptr, g_desc);
+    tile_desc_kernel<1 << 20><<<(ntiles + 255) / 256, 256>>>(tile_rows, ntiles, M, row_off, 0, 0u, nullptr, nullptr, 0u, nullptr, 22, nullptr, nullptr, g_desc);
     if (getenv("GRID")) g_grid = atoi(getenv("GRID"));
     CK(hipDeviceSynchronize());
     printf("P=%llu partials, %u tiles of %u rows x %u (%u per tile), algorithmic bytes %.2f GB\n", (unsigned long long)P, ntiles, rpt,
@@ -136,8 +136,9 @@ int main(int argc, char **argv) {
         {"radix NT256 cap1536 full", 1536, run<256, 0, 1536>}, {"radix NT256 cap1536 nosort", 1536, run<256, 1, 1536>},
         {"radix NT256 cap1536 nolb", 1536, run<256, 2, 1536>}, {"radix NT256 cap1536 nosort+nolb", 1536, run<256, 3, 1536>},
         {"radix NT256 cap1536 latecount", 1536, run<256, 8, 1536>},
-        {"radix NT512 cap3072 full", 3072, run<512, 0, 3072>}, {"radix NT512 cap2048 full", 2048, run<512, 0, 2048>},
-        {"radix NT256 cap2048 full", 2048, run<256, 0, 2048>}, {"radix NT256 cap1280 full", 1280, run<256, 0, 1280>},
+        {"radix NT256 cap1536 4wg", 1536, run<256, 0, 1536, 4>}, {"radix NT256 cap1792 full", 1792, run<256, 0, 1792>},
+        {"radix NT256 cap2048 full", 2048, run<256, 0, 2048>}, {"radix NT256 cap1280 6wg", 1280, run<256, 0, 1280, 6>},
+        {"radix NT512 cap3072 full", 3072, run<512, 0, 3072>},
         {"runs NT1024 full", 3072, run_runs<1024, 0>},
     };
     if (getenv("CHECK_GRIDS")) {
