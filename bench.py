@@ -301,6 +301,14 @@ def main():
             out["cpu_baseline"] = cpu_baseline(csc, csr, n, args.cpu_partials, np_dtype)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         if world == 1:
+            # the reference's own closed-form prediction for this input (SimOuterSPACE.cpp:176-238), beside the
+            # measurement: simulated cycles of a 256-PE OuterSPACE at 85 B/cycle of DRAM, and the DRAM bytes it prices
+            from outerspace_amd import cost_model
+            torch.cuda.synchronize()
+            pred = cost_model.analytical(csc[0], csc[1], csr[0], value_size=np.dtype(np_dtype).itemsize)
+            pred["note"] = ("OuterSPACE analytical model restated from the reference (not a measurement): cycles of the "
+                            "simulated accelerator, 64-B-aligned DRAM bytes per task")
+            out["cost_model"] = pred
             # HBM bytes per launch of the dominant kernel from the PMC counters: they cannot be collected from inside
             # this process (rocprofv3 --pmc wraps it, separate passes), so the figure recorded for exactly this
             # workload under profiles/ is attached when there is one; otherwise null
