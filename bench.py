@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--partial-capacity", type=int, default=0)
     ap.add_argument("--cpu-baseline", type=int, default=1, help="time the CPU reference on a k-slab (rank 0, N=1)")
     ap.add_argument("--cpu-partials", type=float, default=2.5e8, help="partial products in the CPU sample slab")
+    ap.add_argument("--stream-output", action="store_true",
+                    help="single GPU: hand every finished row panel to a consumer (checksum) and drop it; C is never resident")
     ap.add_argument("--shard", default="rows", choices=["rows", "k"],
                     help="multi-GPU decomposition: rows = every rank computes a range of output rows from the replicated "
                          "operands (no exchange); k = shard the shared dimension, exchange partial CSRs over RCCL, merge")
@@ -199,7 +201,24 @@ def main():
     ctx = S.Context(dev_index)
     ptrs = [t.data_ptr() for t in (*csc, *csr)]
 
-    if not use_dist:
+    if not use_dist and args.stream_output:
+        # C never resident: every finished row panel is checksummed on the device and dropped (the way to run
+        # products whose result does not fit, e.g. Graph500 parameters at scale 22)
+        from outerspace_amd.distributed import _as_tensor
+
+        def step(checksum=False):
+            acc = {"sum": 0.0, "nnz": 0}
+
+            def on_panel(p):
+                acc["nnz"] += p["nnz"]
+                if checksum and p["nnz"]:
+                    acc["sum"] += float(_as_tensor(p["vals"], p["nnz"], "<f8" if args.dtype == "f64" else "<f4", device, tdtype)
+                                        .sum(dtype=torch.float64))
+            info = ctx.spgemm_csc_csr_panels(np_dtype, n, n, n, ptrs, on_panel, partial_capacity=args.partial_capacity)
+            assert acc["nnz"] == info["nnz_c"]
+            info["val_sum_global"] = acc["sum"]
+            return info
+    elif not use_dist:
         def step(checksum=False):
             res = ctx.spgemm_csc_csr_device(np_dtype, n, n, n, ptrs, validate=False,
                                             partial_capacity=args.partial_capacity)
@@ -285,7 +304,7 @@ def main():
                                     f"duplicates removed, self-product C=A*A, CSC x CSR -> CSR") if args.workload == "rmat" else
                                    "web-Google-shaped synthetic pattern matrix (916428 vertices, power-law degrees), self-product",
                        "n": n, "nnz_a": nnz_a, "partials": P, "nnz_c": nnz_c,
-                       "parallelism": "single GPU" if world == 1 else (
+                       "parallelism": ("single GPU, output streamed panel by panel (never resident)" if args.stream_output else "single GPU") if world == 1 else (
                            f"k-sharded over {world} GPUs + RCCL all-to-all of partial CSRs" if args.shard == "k" else
                            f"output rows sharded over {world} GPUs (operands replicated, result row-sharded, no exchange)")},
             "gflops": 2 * P / (ms_step * 1e-3) / 1e9, "partials_per_s": P / (ms_step * 1e-3),

@@ -119,6 +119,33 @@ int osp_spgemm_csc_csr(osp_context_t ctx, osp_dtype_t dtype, uint64_t M, uint64_
                        osp_memspace_t space, const osp_config_t *cfg, osp_result_t *result);
 
 /*
+ * The same product, STREAMED: output rows are merged in consecutive row panels (the library's unit of work when the
+ * partial products exceed the staging memory) and every finished panel is handed to `fn` at once; its buffers are
+ * reused for the next panel, so C is never resident as a whole -- the only way to run products whose result does not
+ * fit the GPU (R-MAT-22 with Graph500 parameters has nnzC ~ 7e10).  Inside the callback the panel's
+ * arrays are complete device memory (nothing pending on them); work the callback queues on the context's stream
+ * is waited for before the buffers are reused, anything else must be finished before it returns.  A non-zero return
+ * aborts the product with OSP_ERR_ARG.  Panels arrive in row order and tile [0, M) (or the row shard) exactly.
+ * `info` (may be NULL) receives the same counters osp_result_info reports.  No reference counterpart: the reference
+ * materialises all partial products and the whole result in host vectors (SimSpGEMM.cpp:265-281).
+ */
+typedef struct osp_panel {
+    uint64_t row_begin, row_end; /* output rows [row_begin, row_end) */
+    uint64_t nnz;                /* entries of the panel */
+    const int64_t *rowptr;       /* device, row_end - row_begin + 1 offsets into colidx/vals, rowptr[0] = 0 */
+    const uint32_t *colidx;      /* device, ascending inside a row */
+    const void *vals;            /* device, dtype of the call */
+    uint32_t index, count;       /* this is panel `index` of `count` */
+    uint32_t reserved[2];
+} osp_panel_t;
+typedef int (*osp_panel_fn)(const osp_panel_t *panel, void *user);
+int osp_spgemm_csc_csr_panels(osp_context_t ctx, osp_dtype_t dtype, uint64_t M, uint64_t K, uint64_t N,
+                              const int64_t *a_colptr, const uint32_t *a_rowidx, const void *a_vals,
+                              const int64_t *b_rowptr, const uint32_t *b_colidx, const void *b_vals,
+                              osp_memspace_t space, const osp_config_t *cfg, osp_panel_fn fn, void *user,
+                              osp_result_info_t *info);
+
+/*
  * Same product from COO operands in any order: the conversion the reference does on the host with two
  * std::sorts -- csc = coo2csr<true>(A, K), csr = coo2csr(B, K), SimSpGEMM.cpp:878-879 / :102-152 -- runs on the
  * GPU (stable radix sorts by (column,row) and (row,column)).  A duplicate coordinate in either operand returns

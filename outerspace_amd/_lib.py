@@ -45,10 +45,21 @@ class ResultInfo(C.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+class Panel(C.Structure):
+    """osp_panel_t: one finished row panel of a streamed product (device pointers)."""
+    _fields_ = [("row_begin", C.c_uint64), ("row_end", C.c_uint64), ("nnz", C.c_uint64),
+                ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("vals", C.c_void_p),
+                ("index", C.c_uint32), ("count", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+
+
+PANEL_FN = C.CFUNCTYPE(C.c_int, C.POINTER(Panel), C.c_void_p)
+
+
 # every symbol include/outerspace_spgemm.h declares
 EXPORTS = [
     "osp_context_create", "osp_context_create_on_stream", "osp_context_destroy", "osp_context_trim",
-    "osp_config_default", "osp_last_error_string", "osp_status_string", "osp_spgemm_csc_csr", "osp_spgemm_coo",
+    "osp_config_default", "osp_last_error_string", "osp_status_string", "osp_spgemm_csc_csr", "osp_spgemm_csc_csr_panels",
+    "osp_spgemm_coo",
     "osp_merge_csr_parts", "osp_result_info", "osp_result_copy_csr", "osp_result_device_ptrs",
     "osp_result_destroy", "osp_mtx_read", "osp_host_free", "osp_coo_to_compressed_f32",
     "osp_coo_to_compressed_f64", "osp_spgemm_mtx", "osp_result_write_mtx",
@@ -79,6 +90,8 @@ def lib():
     L.osp_config_default.restype = None
     L.osp_spgemm_csc_csr.argtypes = [vp, i32, u64, u64, u64, vp, vp, vp, vp, vp, vp, i32,
                                      C.POINTER(Config), C.POINTER(vp)]
+    L.osp_spgemm_csc_csr_panels.argtypes = [vp, i32, u64, u64, u64, vp, vp, vp, vp, vp, vp, i32, C.POINTER(Config), PANEL_FN, vp,
+                                            C.POINTER(ResultInfo)]
     L.osp_spgemm_coo.argtypes = [vp, i32, u64, u64, u64, u64, vp, vp, vp, u64, vp, vp, vp, i32, C.POINTER(Config), C.POINTER(vp)]
     L.osp_merge_csr_parts.argtypes = [vp, i32, u64, u64, i32, C.POINTER(vp), C.POINTER(vp),
                                       C.POINTER(vp), i32, C.POINTER(Config), C.POINTER(vp)]

@@ -61,7 +61,47 @@ struct Context {
         size_t step = p / 8;
         return (bytes + step - 1) / step * step;
     }
+    // Debugging aid: OSP_GUARD=1 gives every buffer its own allocation with 4 KiB of 0xA5 before it and from the
+    // end of the REQUESTED size to the end of the allocation, and checks both zones when the buffer is released --
+    // a kernel that writes a little past (or before) its buffer is named instead of corrupting a neighbour.
+    // (Bucket rounding normally hides such writes unless the request happens to fill its bucket.)
+    static constexpr size_t kGuard = 4096;
+    struct GuardRec { char *base; size_t total, bytes; };
+    std::map<void *, GuardRec> guarded;
+    static bool guard_mode() { static const bool g = getenv("OSP_GUARD") != nullptr; return g; }
+    void *alloc_guarded(size_t bytes) {
+        const size_t total = bucket(bytes + 2 * kGuard);
+        char *base = nullptr;
+        hipError_t e = hipMalloc((void **)&base, total);
+        if (e != hipSuccess) { (void)hipGetLastError(); throw Error(OSP_ERR_ALLOC, "hipMalloc of " + std::to_string(total) + " bytes failed (guard mode)"); }
+        (void)hipMemsetAsync(base, 0xA5, kGuard, stream);
+        (void)hipMemsetAsync(base + kGuard + bytes, 0xA5, total - kGuard - bytes, stream);
+        guarded[base + kGuard] = GuardRec{base, total, bytes};
+        return base + kGuard;
+    }
+    void release_guarded(void *p) {
+        auto it = guarded.find(p);
+        if (it == guarded.end()) return;
+        const GuardRec g = it->second;
+        guarded.erase(it);
+        (void)hipStreamSynchronize(stream);
+        const size_t tail = std::min<size_t>(g.total - kGuard - g.bytes, 1 << 20);
+        std::vector<unsigned char> h(kGuard + tail);
+        (void)hipMemcpy(h.data(), g.base, kGuard, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h.data() + kGuard, g.base + kGuard + g.bytes, tail, hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < h.size(); i++) {
+            if (h[i] != 0xA5) {
+                const long long off = i < kGuard ? (long long)i - (long long)kGuard : (long long)(i - kGuard);
+                fprintf(stderr, "[osp] OSP_GUARD: buffer of %zu bytes was written %s it: first damaged byte at %s%lld (value 0x%02x)\n",
+                        g.bytes, i < kGuard ? "BEFORE" : "PAST the end of", i < kGuard ? "offset " : "end+", off, h[i]);
+                fflush(stderr);
+                abort();
+            }
+        }
+        (void)hipFree(g.base);
+    }
     void *alloc(size_t bytes) {
+        if (guard_mode()) return alloc_guarded(bytes ? bytes : 1);
         size_t b = bucket(bytes ? bytes : 1);
         // best fit among pooled blocks: anything from b to 1.5 b is reused (buffer sizes drift from panel to
         // panel and from call to call; hipMalloc / hipFree of multi-GB blocks cost far more than the slack)
@@ -97,6 +137,7 @@ struct Context {
     }
     void release(void *p) {
         if (!p) return;
+        if (guard_mode()) { release_guarded(p); return; }
         auto it = live.find(p);
         if (it == live.end()) return;
         free_list.emplace(it->second, p);
@@ -356,12 +397,19 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
     OSP_HIP(hipGetLastError());  // a rejected launch must not pass silently
 }
 
+// Streaming mode (osp_spgemm_csc_csr_panels): every row panel is handed to the caller as soon as it is merged and
+// its buffers are reused for the next one -- C is never resident as a whole.
+struct PanelSink {
+    osp_panel_fn fn;
+    void *user;
+};
+
 // ---- stages shared by both entry points: partial products of each row -> final CSR ----------------
 template <class T>
 static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_t M_all, uint64_t N,
                            const uint64_t *d_row_off, const uint32_t *d_arow, const uint64_t *d_chunk_start,
                            uint64_t P, uint64_t cap_cfg, PhaseTimer &tm, uint64_t r_lo = 0, uint64_t r_hi = ~0ull,
-                           uint64_t off_lo = 0) {
+                           uint64_t off_lo = 0, const PanelSink *sink = nullptr) {
     // output rows [r_lo, r_hi) only (row-sharded multi-GPU mode); P = their partial products, off_lo = row_off[r_lo]
     if (r_hi == ~0ull) r_hi = M_all;
     const uint64_t M = r_hi - r_lo;
@@ -375,26 +423,40 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     // runs 6.9 ms per 2.7e8 partial products (16 chunks of 16 per row), so radix is what ships.
     const int colbits = std::max(1, bits_for(N));
 
-    res->rowptr = (int64_t *)ctx->alloc((M + 1) * sizeof(int64_t));
+    if (!sink) res->rowptr = (int64_t *)ctx->alloc((M + 1) * sizeof(int64_t));
     if (P == 0) {
-        OSP_HIP(hipMemsetAsync(res->rowptr, 0, (M + 1) * sizeof(int64_t), s));
         res->info.nnz_c = 0;
+        if (sink) {
+            // one empty panel, so that the caller sees every row exactly once
+            int64_t *zr = sc.get<int64_t>(M + 1);
+            OSP_HIP(hipMemsetAsync(zr, 0, (M + 1) * sizeof(int64_t), s));
+            OSP_HIP(hipStreamSynchronize(s));
+            res->info.panels = 1;
+            const osp_panel_t pd{r_lo, r_hi, 0, zr, nullptr, nullptr, 0, 1, {0, 0}};
+            if (sink->fn(&pd, sink->user)) throw Error(OSP_ERR_ARG, "panel callback returned non-zero");
+            return;
+        }
+        OSP_HIP(hipMemsetAsync(res->rowptr, 0, (M + 1) * sizeof(int64_t), s));
         return;
     }
     // ---- final CSR arrays at an upper bound: nnz(C) <= sum_i min(U_i, N) -------------------------------
     const uint64_t E = 4 + sizeof(T);
     uint64_t cap_c;
+    uint64_t *ub = sc.get<uint64_t>(M + 1);  // exclusive scan of the per-row bounds (kept: streaming sizes panels with it)
     {
         Scratch us(ctx);
-        uint64_t *ub = us.get<uint64_t>(M + 1);
         uint64_t *ub_tmp = us.get<uint64_t>(scan_scratch_entries(M + 1));
         device_exclusive_scan<RowUpperBound, uint64_t>(RowUpperBound{d_row_off + r_lo, N}, M, ub, ub_tmp, s);
         cap_c = d2h(ub + M, s);
     }
-    res->colidx = (uint32_t *)ctx->alloc(std::max<uint64_t>(cap_c, 1) * sizeof(uint32_t));
-    res->vals = ctx->alloc(std::max<uint64_t>(cap_c, 1) * sizeof(T));
-    uint32_t *c_col = res->colidx;
-    T *c_val = (T *)res->vals;
+    uint32_t *c_col = nullptr;
+    T *c_val = nullptr;
+    if (!sink) {
+        res->colidx = (uint32_t *)ctx->alloc(std::max<uint64_t>(cap_c, 1) * sizeof(uint32_t));
+        res->vals = ctx->alloc(std::max<uint64_t>(cap_c, 1) * sizeof(T));
+        c_col = res->colidx;
+        c_val = (T *)res->vals;
+    }
     // ---- panels: consecutive rows whose partial products fit the staging capacity --------------
     // What is left after the output is shared by the staging buffer and, for long rows, the split
     // buffer and its temporary output (each up to one panel): budget a third of it, with slack.
@@ -402,7 +464,8 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     OSP_HIP(hipMemGetInfo(&free_b, &total_b));
     free_b += ctx->pooled_bytes;
     uint64_t cap = cap_cfg;
-    if (cap == 0) cap = std::max<uint64_t>((uint64_t)(free_b * 0.85 / (3.3 * E)), 1ull << 20);
+    // streaming: the panel's output buffer (at most one record per partial product) comes out of the same budget
+    if (cap == 0) cap = std::max<uint64_t>((uint64_t)(free_b * 0.85 / ((sink ? 4.4 : 3.3) * E)), 1ull << 20);
     cap = std::min<uint64_t>(cap, 0xfffffff0ull);  // staging positions are u32
     if (getenv("OSP_VERBOSE"))
         fprintf(stderr, "[osp] M=%llu N=%llu P=%llu nnzC<=%llu (%.1f GB) free %.1f GB -> staging capacity %llu partial products (%.1f GB)\n",
@@ -442,6 +505,38 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     Part<T> *stage = sc.get<Part<T>>(max_panel);
     uint64_t *out_nnz = sc.get<uint64_t>((uint64_t)npanels + 1);  // nnz written before panel p
     OSP_HIP(hipMemsetAsync(out_nnz, 0, sizeof(uint64_t), s));
+    if (sink) {
+        // ---- streaming: one output buffer sized for the largest panel's bound, reused by every panel ----
+        std::vector<uint64_t> h_ub(npanels + 1);
+        for (uint32_t p = 0; p <= npanels; p++) h_ub[p] = d2h(ub + (bounds[p] - r_lo), s);
+        uint64_t max_out = 1;
+        for (uint32_t p = 0; p < npanels; p++) max_out = std::max(max_out, h_ub[p + 1] - h_ub[p]);
+        c_col = sc.get<uint32_t>(max_out);
+        c_val = sc.get<T>(max_out);
+        int64_t *prow = sc.get<int64_t>(max_rows_panel + 1);
+        uint64_t *cells = sc.get<uint64_t>(2);  // [0] = 0 (entries before the panel), [1] = entries of the panel
+        uint64_t nnz_total = 0;
+        for (uint32_t p = 0; p < npanels; p++) {
+            const uint64_t r0 = bounds[p], r1 = bounds[p + 1];
+            const uint64_t base = (npanels == 1) ? off_lo : h_off[r0];
+            const uint64_t count = (npanels == 1) ? P : h_off[r1] - base;
+            tm.begin(PH_MUL);
+            if (count) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm);
+            tm.end(PH_MUL);
+            tm.begin(PH_MERGE);
+            OSP_HIP(hipMemsetAsync(cells, 0, 2 * sizeof(uint64_t), s));
+            MergeIO<T> io{stage, d_row_off, r0, r1, base, prow - r0, c_col, c_val, cells, cells + 1};
+            merge_panel<T>(ctx, res, tm, io, colbits);
+            tm.end(PH_MERGE);
+            const uint64_t nnz_p = d2h(cells + 1, s);  // synchronises: the panel is complete
+            nnz_total += nnz_p;
+            const osp_panel_t pd{r0, r1, nnz_p, prow, c_col, c_val, p, npanels, {0, 0}};
+            if (sink->fn(&pd, sink->user)) throw Error(OSP_ERR_ARG, "panel callback returned non-zero");
+            OSP_HIP(hipStreamSynchronize(s));  // whatever the callback queued on this stream reads the buffers
+        }
+        res->info.nnz_c = nnz_total;
+        return;
+    }
 
     for (uint32_t p = 0; p < npanels; p++) {
         const uint64_t r0 = bounds[p], r1 = bounds[p + 1];
@@ -533,7 +628,7 @@ template <class T>
 static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint64_t N, const int64_t *a_colptr_in,
                         const uint32_t *a_rowidx_in, const T *a_vals_in, const int64_t *b_rowptr_in,
                         const uint32_t *b_colidx_in, const T *b_vals_in, osp_memspace_t space,
-                        const osp_config_t &cfg) {
+                        const osp_config_t &cfg, const PanelSink *sink = nullptr) {
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
     PhaseTimer tm(s);
@@ -651,7 +746,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         P_rows = h_b[G + 1 + cfg.row_shard_index + 1] - off_lo;
         res->info.partials = P_rows;
     }
-    merge_pipeline<T>(ctx, res, prod, M, N, row_off, arow, chunk_start, P_rows, cfg.partial_capacity, tm, r_lo, r_hi, off_lo);
+    merge_pipeline<T>(ctx, res, prod, M, N, row_off, arow, chunk_start, P_rows, cfg.partial_capacity, tm, r_lo, r_hi, off_lo, sink);
 
     OSP_HIP(hipEventRecord(ev1, s));
     OSP_HIP(hipStreamSynchronize(s));
@@ -927,6 +1022,45 @@ int osp_spgemm_csc_csr(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, uint64
     }
     *result = (osp_result_t)res;
     return OSP_OK;
+}
+
+int osp_spgemm_csc_csr_panels(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, uint64_t K, uint64_t N,
+                              const int64_t *a_colptr, const uint32_t *a_rowidx, const void *a_vals,
+                              const int64_t *b_rowptr, const uint32_t *b_colidx, const void *b_vals,
+                              osp_memspace_t space, const osp_config_t *cfg_, osp_panel_fn fn, void *user,
+                              osp_result_info_t *info) {
+    Context *ctx = (Context *)ctx_;
+    if (!ctx || !fn) return fail(OSP_ERR_ARG, "null context or panel callback");
+    if (!a_colptr || !b_rowptr) return fail(OSP_ERR_ARG, "null pointer array");
+    if (dtype != OSP_F32 && dtype != OSP_F64) return fail(OSP_ERR_ARG, "dtype must be OSP_F32 or OSP_F64");
+    if (space != OSP_HOST && space != OSP_DEVICE) return fail(OSP_ERR_ARG, "bad memory space");
+    if (M >= 0xffffffffull || N > 0xffffffffull || K >= 0xffffffffull) return fail(OSP_ERR_ARG, "dimension exceeds the u32 index type");
+    osp_config_t cfg;
+    if (cfg_) cfg = *cfg_; else osp_config_default(&cfg);
+    Result *res = new Result;  // carries the counters only: no output arrays are attached in streaming mode
+    res->ctx = ctx;
+    res->dtype = dtype;
+    res->info.M = M; res->info.K = K; res->info.N = N; res->info.dtype = dtype;
+    const PanelSink sink{fn, user};
+    int st = OSP_OK;
+    try {
+        OSP_HIP(hipSetDevice(ctx->device));
+        if (dtype == OSP_F32)
+            spgemm_impl<float>(ctx, res, M, K, N, a_colptr, a_rowidx, (const float *)a_vals, b_rowptr, b_colidx,
+                               (const float *)b_vals, space, cfg, &sink);
+        else
+            spgemm_impl<double>(ctx, res, M, K, N, a_colptr, a_rowidx, (const double *)a_vals, b_rowptr, b_colidx,
+                                (const double *)b_vals, space, cfg, &sink);
+        if (info) *info = res->info;
+    } catch (const Error &e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        st = fail(e.status, "%s", e.what());
+    } catch (const std::exception &e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        st = fail(OSP_ERR_ALLOC, "%s", e.what());
+    }
+    destroy_result(res);
+    return st;
 }
 
 int osp_spgemm_coo(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, uint64_t K, uint64_t N, uint64_t nnz_a,

@@ -775,11 +775,22 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG>())) vo
         if (npass == 0) {  // nothing was sorted (empty tile): the payload is still implicit
             for (uint32_t i = tid; i < n; i += NT) spos[i] = (uint16_t)i;
         }
-        // the values leave the registers now; the barriers inside the scan below order this before the run sums
+        // the values: read again (the tile went through L2 a few microseconds ago) rather than held in 18 registers
+        // through the sort -- that is what lets five workgroups per CU run without spilling.  The barriers inside the
+        // scan below order the LDS writes before the run sums.
+        {
+            const Part<T> *__restrict__ stg = lvl.stage[d.lvl];
+            T vq[LPT];
 #pragma unroll
-        for (int q = 0; q < LPT; q++) {
-            const uint32_t i = tid + q * NT;
-            if (i < n) sval[i] = lrec[q].val();
+            for (int q = 0; q < LPT; q++) {
+                const uint32_t i = tid + q * NT;
+                vq[q] = load_part_words(i < n ? &stg[s + i] : reinterpret_cast<const Part<T> *>(desc)).val();  // clamped, branch-free
+            }
+#pragma unroll
+            for (int q = 0; q < LPT; q++) {
+                const uint32_t i = tid + q * NT;
+                if (i < n) sval[i] = vq[q];
+            }
         }
         if (npass == 0) __syncthreads();
         // head flags + exclusive scan (blocked: thread owns IPT consecutive sorted entries)

@@ -172,6 +172,35 @@ class Context:
                                                  C.byref(cfg), C.byref(h)))
         return CsrResult(self, h)
 
+    def spgemm_csc_csr_panels(self, dtype, M, K, N, ptrs, on_panel, *, device=True, validate=False, partial_capacity=0,
+                              k_range=None, row_shard=None):
+        """Streamed product (``osp_spgemm_csc_csr_panels``): C is never resident as a whole.  ``ptrs`` = the six operand
+        addresses (ints; device memory unless device=False).  ``on_panel(p)`` is called once per finished row panel, in
+        row order, with a dict: row_begin, row_end, nnz, index, count and the DEVICE addresses rowptr / colidx / vals
+        (valid only during the call; wrap them zero-copy, e.g. ``distributed._as_tensor``).  An exception raised by
+        the callback aborts the product and is re-raised.  Returns the info dict (counters, phase times)."""
+        cfg = self._config(validate, partial_capacity, k_range, row_shard)
+        err = []
+
+        def tramp(pp, _user):
+            p = pp.contents
+            try:
+                on_panel({"row_begin": p.row_begin, "row_end": p.row_end, "nnz": p.nnz, "index": p.index, "count": p.count,
+                          "rowptr": p.rowptr or 0, "colidx": p.colidx or 0, "vals": p.vals or 0})
+                return 0
+            except BaseException as e:  # never let an exception cross the C frames
+                err.append(e)
+                return 1
+
+        fn = _lib.PANEL_FN(tramp)
+        info = _lib.ResultInfo()
+        st = _lib.lib().osp_spgemm_csc_csr_panels(self._h, _DT[np.dtype(dtype)], M, K, N, *[C.c_void_p(int(p)) for p in ptrs],
+                                                  _lib.OSP_DEVICE if device else _lib.OSP_HOST, C.byref(cfg), fn, None, C.byref(info))
+        if err:
+            raise err[0]
+        _lib.check(st)
+        return info.as_dict()
+
     def merge_csr_parts(self, M, N, parts, *, partial_capacity=0):
         """Sum CSR matrices of equal shape.  parts: list of (rowptr, colidx, vals) numpy triples."""
         dt = np.dtype(parts[0][2].dtype)

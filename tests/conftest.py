@@ -1,4 +1,7 @@
 import os
+
+# errors of the HIP runtime are silent at its default log level; a run that dies should say why
+os.environ.setdefault("AMD_LOG_LEVEL", "1")
 import sys
 
 import pytest

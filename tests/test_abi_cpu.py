@@ -27,6 +27,7 @@ def test_struct_layouts_match_header():
     import ctypes
     # osp_config_t: int, u64, u64, u64, int[8]; osp_result_info_t ends with two u32 and an int
     assert ctypes.sizeof(_lib.Config) == 8 + 8 + 8 + 8 + 32
+    assert ctypes.sizeof(_lib.Panel) == 3 * 8 + 3 * 8 + 4 * 4  # osp_panel_t: three u64, three pointers, four u32
     cfg = _lib.Config()
     _lib.lib().osp_config_default(ctypes.byref(cfg))
     assert cfg.validate == 1 and cfg.partial_capacity == 0 and cfg.k_end == 0

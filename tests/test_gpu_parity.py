@@ -444,3 +444,59 @@ def test_row_shards_tile_the_product(ctx, port):
             assert r.info["partials"] <= want["partials"] / G * 1.5 + 5000  # balanced by work
             end, P = r1, P + r.info["partials"]
         assert end == n and P == want["partials"]
+
+
+def test_streamed_panels_equal_the_resident_product(ctx, port):
+    """osp_spgemm_csc_csr_panels: panels arrive in row order, tile the rows exactly, and put together are the CSR the
+    resident call returns (which is the oracle's); also as one row shard of three, and with an empty product."""
+    import torch
+    from outerspace_amd import spgemm as S
+    from outerspace_amd.distributed import _as_tensor
+    n, rows, cols, vals = gen.rmat_coo(12, 16, "mild", seed=4)
+    acsc, bcsr = S.coo_to_csc(n, rows, cols, vals), S.coo_to_csr(n, rows, cols, vals)
+    want = port.spgemm(n, n, n, *acsc, *bcsr)
+    dev = torch.device("cuda:0")
+    t = [torch.from_numpy(a.astype(np.int32) if a.dtype == np.uint32 else a).to(dev) for a in (*acsc, *bcsr)]
+    ptrs = [x.data_ptr() for x in t]
+
+    def collect(**kw):
+        got = []
+
+        def on_panel(p):
+            nr = p["row_end"] - p["row_begin"]
+            rp = _as_tensor(p["rowptr"], nr + 1, "<i8", dev, torch.int64).cpu().numpy()
+            ci = _as_tensor(p["colidx"], p["nnz"], "<i4", dev, torch.int32).cpu().numpy().view(np.uint32)
+            cv = _as_tensor(p["vals"], p["nnz"], "<f8", dev, torch.float64).cpu().numpy()
+            got.append((dict(p), rp, ci, cv))
+        info = ctx.spgemm_csc_csr_panels(np.float64, n, n, n, ptrs, on_panel, **kw)
+        return info, got
+
+    P = want["partials"]
+    for cap in (0, P // 5 + 1):   # one panel; several panels
+        info, got = collect(partial_capacity=cap)
+        assert info["nnz_c"] == len(want["colidx"]) and info["partials"] == P and info["panels"] == len(got)
+        assert (cap == 0) == (len(got) == 1)
+        assert got[0][0]["row_begin"] == 0 and got[-1][0]["row_end"] == n
+        assert all(a[0]["row_end"] == b[0]["row_begin"] for a, b in zip(got, got[1:]))
+        assert [g[0]["index"] for g in got] == list(range(len(got))) and all(g[0]["count"] == len(got) for g in got)
+        for d, rp, ci, cv in got:
+            lo, hi = want["rowptr"][d["row_begin"]], want["rowptr"][d["row_end"]]
+            assert rp[0] == 0 and rp[-1] == d["nnz"] == hi - lo
+            assert np.array_equal(rp, want["rowptr"][d["row_begin"]:d["row_end"] + 1] - lo)
+            assert np.array_equal(ci, want["colidx"][lo:hi]) and np.array_equal(cv, want["vals"][lo:hi])
+    # a row shard, streamed
+    info, got = collect(partial_capacity=P // 7 + 1, row_shard=(1, 3))
+    r0, r1 = info["row_begin"], info["row_end"]
+    assert 0 < r0 < r1 < n and got[0][0]["row_begin"] == r0 and got[-1][0]["row_end"] == r1
+    assert sum(g[0]["nnz"] for g in got) == want["rowptr"][r1] - want["rowptr"][r0] == info["nnz_c"]
+    # an exception in the callback aborts the product and comes back out
+    def boom(p):
+        raise KeyError("stop")
+    with pytest.raises(KeyError):
+        ctx.spgemm_csc_csr_panels(np.float64, n, n, n, ptrs, boom)
+    # empty product: one empty panel covering every row
+    z = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    e = torch.zeros(1, dtype=torch.float64, device=dev)
+    seen = []
+    info = ctx.spgemm_csc_csr_panels(np.float64, n, n, n, [z.data_ptr(), e.data_ptr(), e.data_ptr()] * 2, lambda p: seen.append(dict(p)))
+    assert info["nnz_c"] == 0 and len(seen) == 1 and (seen[0]["row_begin"], seen[0]["row_end"], seen[0]["nnz"]) == (0, n, 0)
