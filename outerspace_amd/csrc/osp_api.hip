@@ -333,35 +333,56 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         // ---- tiles over the segments; a tile never spans two long rows ----
         p1 = plan_tiles(ctx, sc, vrow_off, 0, nvirt, 0, kCap, max_rows, vfirst);
         vptr = (int64_t *)sc.get<uint64_t>(nvirt + 1);
+        lv.stage[1] = qstage; lv.row_off[1] = vrow_off; lv.base[1] = 0; lv.c_rowptr[1] = vptr;
         if (p1.nlong) {
-            // segments that are still too long (one column hit by thousands of products): global stable sort on
-            // (segment, col), run sums in place in the second buffer
+            // ---- segments that are still too long ----
             const uint32_t nseg_long = p1.nlong;
-            res->info.sorted_segments += nseg_long;
-            uint64_t *soff = sc.get<uint64_t>((uint64_t)nseg_long + 1);
-            device_exclusive_scan<HeavyLen, uint64_t>(HeavyLen{p1.long_rows, vrow_off}, nseg_long, soff, hscan_tmp, s);
-            const uint64_t ns = d2h(soff + nseg_long, s);
-            res->info.sorted_partials += ns;
             seg_src = sc.get<uint64_t>(nseg_long);
             seg_nnz = sc.get<uint32_t>(nvirt + 1);
-            uint64_t *keys[2] = {sc.get<uint64_t>(ns), sc.get<uint64_t>(ns)};
-            uint32_t *poss[2] = {sc.get<uint32_t>(ns), sc.get<uint32_t>(ns)};
-            uint32_t *hist = sc.get<uint32_t>(sort_hist_entries(ns));
-            uint32_t *hist_tmp = sc.get<uint32_t>(scan_scratch_entries(sort_hist_entries(ns)));
-            heavy_fill_kernel<<<grid_for(ns, 256), 256, 0, s>>>(p1.long_rows, soff, nseg_long, vrow_off, 0, colbits, (const char *)qstage,
-                                                                (uint32_t)sizeof(Part<T>), ns, keys[0], poss[0]);
-            const int cur = device_radix_sort_pairs<uint64_t>(keys, poss, ns, colbits + bits_for(nseg_long), hist, hist_tmp, s);
-            T *sorted_val = sc.get<T>(ns);
-            heavy_gather_kernel<T><<<grid_for(ns, 256), 256, 0, s>>>(poss[cur], qstage, ns, sorted_val);
-            uint64_t *headscan = sc.get<uint64_t>(ns + 1);
-            uint64_t *headscan_tmp = sc.get<uint64_t>(scan_scratch_entries(ns));
-            device_exclusive_scan<HeavyHeadFlag, uint64_t>(HeavyHeadFlag{keys[cur]}, ns, headscan, headscan_tmp, s);
-            heavy_reduce_kernel<T><<<grid_for(ns, 256), 256, 0, s>>>(keys[cur], sorted_val, headscan, ns, p1.long_rows, soff, nseg_long,
-                                                                     vrow_off, 0, colbits, qstage);
-            heavy_rows_kernel<<<grid_for(nseg_long, 256), 256, 0, s>>>(p1.long_rows, soff, nseg_long, headscan, seg_nnz);
+            lv.heavy_nnz[1] = seg_nnz;
+            // by length: up to kBigTileCap -> one big LDS tile each, reduced in place; beyond -> global sort
+            uint32_t *hscan = sc.get<uint32_t>((uint64_t)nseg_long + 1);
+            const SegHugeFlag hf{p1.long_rows, vrow_off, (uint32_t)kBigTileCap};
+            device_exclusive_scan<SegHugeFlag, uint32_t>(hf, nseg_long, hscan, (uint32_t *)hscan_tmp, s);
+            const uint32_t nhuge = d2h(hscan + nseg_long, s), nmid = nseg_long - nhuge;
+            uint32_t *huge_list = sc.get<uint32_t>(nhuge), *mid_list = sc.get<uint32_t>(nmid);
+            seg_partition_kernel<<<grid_for(nseg_long, 256), 256, 0, s>>>(hf, hscan, nseg_long, huge_list, mid_list);
+            res->info.sorted_segments += nhuge;
+            if (nmid) {
+                TileDesc *bdesc = sc.get<TileDesc>(nmid);
+                seg_tile_desc_kernel<<<grid_for(nmid, 256), 256, 0, s>>>(mid_list, nmid, vrow_off, vbase, hbits, nlong, colbits, bdesc);
+                uint32_t *bticket = sc.get<uint32_t>(1);
+                OSP_HIP(hipMemsetAsync(bticket, 0, sizeof(uint32_t), s));
+                const uint32_t bgrid = ctx->cus * (uint32_t)merge_wgs_per_cu<T, kBigTileThreads, kBigTileCap>();
+                merge_tiles_kernel<T, kBigTileThreads, 32, kBigTileCap><<<std::min<uint32_t>(nmid, bgrid), kBigTileThreads, 0, s>>>(
+                    bdesc, nmid, lv, colbits, nullptr, bticket, nullptr, nullptr, nullptr, nullptr);
+            }
+            if (nhuge) {
+                // one output entry fed by more products than any tile holds: global stable sort on (segment, col),
+                // run sums in place in the second buffer
+                uint64_t *soff = sc.get<uint64_t>((uint64_t)nhuge + 1);
+                device_exclusive_scan<HeavyLen, uint64_t>(HeavyLen{huge_list, vrow_off}, nhuge, soff, hscan_tmp, s);
+                const uint64_t ns = d2h(soff + nhuge, s);
+                res->info.sorted_partials += ns;
+                uint64_t *keys[2] = {sc.get<uint64_t>(ns), sc.get<uint64_t>(ns)};
+                uint32_t *poss[2] = {sc.get<uint32_t>(ns), sc.get<uint32_t>(ns)};
+                uint32_t *hist = sc.get<uint32_t>(sort_hist_entries(ns));
+                uint32_t *hist_tmp = sc.get<uint32_t>(scan_scratch_entries(sort_hist_entries(ns)));
+                heavy_fill_kernel<<<grid_for(ns, 256), 256, 0, s>>>(huge_list, soff, nhuge, vrow_off, 0, colbits, (const char *)qstage,
+                                                                    (uint32_t)sizeof(Part<T>), ns, keys[0], poss[0]);
+                const int cur = device_radix_sort_pairs<uint64_t>(keys, poss, ns, colbits + bits_for(nhuge), hist, hist_tmp, s);
+                T *sorted_val = sc.get<T>(ns);
+                heavy_gather_kernel<T><<<grid_for(ns, 256), 256, 0, s>>>(poss[cur], qstage, ns, sorted_val);
+                uint64_t *headscan = sc.get<uint64_t>(ns + 1);
+                uint64_t *headscan_tmp = sc.get<uint64_t>(scan_scratch_entries(ns));
+                device_exclusive_scan<HeavyHeadFlag, uint64_t>(HeavyHeadFlag{keys[cur]}, ns, headscan, headscan_tmp, s);
+                heavy_reduce_kernel<T><<<grid_for(ns, 256), 256, 0, s>>>(keys[cur], sorted_val, headscan, ns, huge_list, soff, nhuge,
+                                                                         vrow_off, 0, colbits, qstage);
+                heavy_rows_kernel<<<grid_for(nhuge, 256), 256, 0, s>>>(huge_list, soff, nhuge, headscan, seg_nnz);
+            }
             heavy_src_inplace_kernel<<<grid_for(nseg_long, 256), 256, 0, s>>>(p1.long_rows, nseg_long, vrow_off, 0, seg_src);
         }
-        lv.stage[1] = qstage; lv.row_off[1] = vrow_off; lv.base[1] = 0; lv.c_rowptr[1] = vptr; lv.heavy_nnz[1] = seg_nnz;
+        lv.heavy_nnz[1] = seg_nnz;
         // ---- one chain: every long row's placeholder is replaced by the tiles of its segments ----
         uint32_t *j0 = sc.get<uint32_t>(nlong), *tb = sc.get<uint32_t>((uint64_t)nlong + 1), *extra = sc.get<uint32_t>((uint64_t)nlong + 1);
         chain_rows_kernel<<<grid_for(nlong + 1, 256), 256, 0, s>>>(p0.long_rows, nlong, p0.tile_rows, p0.ntiles, vbase, p1.tile_rows,

@@ -530,7 +530,9 @@ __device__ unsigned long long osp_merge_prof[16];
 #endif
 
 // ABL: ablation switches for tools/bench_merge.hip only (1 = no sort, 2 = no look-back, 4 = no ticket,
-// 8 = entry count published after the sort instead of by hashing);
+// 8 = entry count published after the sort instead of by hashing).
+// Bit 32 is a real mode, not an ablation: IN-PLACE tiles -- every tile is one over-long segment that is reduced where
+// it lies (records written back over its own beginning, entry count to heavy_nnz); no offset chain, no look-back.
 // the library always instantiates ABL = 0.
 //
 // Persistent workgroups: each takes tiles from the ticket counter until none are left.  The ticket and
@@ -571,7 +573,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG>())) vo
         if (t0 < ntiles) s_dnext = desc[t0];
     }
     __syncthreads();
-    const uint64_t out_base = *out_base_p;
+    const uint64_t out_base = (ABL & 32) ? 0ull : *out_base_p;
     const uint32_t colmask = colbits < 32 ? ((1u << colbits) - 1u) : 0xffffffffu;
     // the first tile's data is requested here; inside the loop the NEXT tile's data is requested while the
     // current tile's output is being written
@@ -638,7 +640,8 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG>())) vo
         // first sort pass (everything behind key0: exactly 2.5 words per entry).
         constexpr uint32_t HS = (uint32_t)kTileCap * 5u / 2u;
         uint32_t *htab = sm.htab();
-        const bool early = nbits > 0 && keybits < 32 && !(ABL & 2) && !(ABL & 8);
+        constexpr bool INPLACE = (ABL & 32) != 0;
+        const bool early = nbits > 0 && keybits < 32 && !(ABL & 2) && !(ABL & 8) && !INPLACE;
         if (early) {
             for (uint32_t i = tid; i < HS; i += NT) htab[i] = 0xffffffffu;
             if (tid == 0) sm.hcount = 0;
@@ -811,9 +814,10 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG>())) vo
         // the tile's unique count is known: wave 0 runs the look-back and then requests the next ticket;
         // the ticket's round trip overlaps the run sums below
         if (w == 0) {
-            const uint64_t excl = (ABL & 2) ? (uint64_t)t * kTileCap
-                                 : early   ? lookback_prefix<false>(tile_status, t, total)  // count already published
-                                           : lookback_prefix<true>(tile_status, t, total);
+            const uint64_t excl = INPLACE   ? 0ull
+                                 : (ABL & 2) ? (uint64_t)t * kTileCap
+                                 : early     ? lookback_prefix<false>(tile_status, t, total)  // count already published
+                                             : lookback_prefix<true>(tile_status, t, total);
             if (lane == 0) {
                 sm.excl = excl;
                 tn_reg = (ABL & 4) ? t + gridDim.x : atomicAdd(ticket, 1u);
@@ -863,11 +867,18 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG>())) vo
         const TileDesc dn = s_dnext;
         // the next tile's HBM reads go out ahead of this tile's writes
         request(dn, tn < ntiles);
-        const uint64_t obase = out_base + sm.excl;
-        for (uint32_t o = tid; o < total; o += NT) { c_col[obase + o] = skey[o]; c_val[obase + o] = sval[o]; }
-        // rows keep their index span through the sort (row is the major key)
-        if (tid < nr) c_rowptr[ra + tid] = (int64_t)(obase + sm.rank[sm.rowo[tid]]);
-        if (t + 1 == ntiles && tid == 0) *out_end_p = obase + total;
+        if constexpr (INPLACE) {
+            // the segment's merged entries go back over its own beginning (everything of it is in LDS by now)
+            Part<T> *outp = const_cast<Part<T> *>(lvl.stage[d.lvl]) + s;
+            for (uint32_t o = tid; o < total; o += NT) outp[o] = Part<T>{skey[o], sval[o]};
+            if (tid == 0) const_cast<uint32_t *>(lvl.heavy_nnz[d.lvl])[ra] = total;
+        } else {
+            const uint64_t obase = out_base + sm.excl;
+            for (uint32_t o = tid; o < total; o += NT) { c_col[obase + o] = skey[o]; c_val[obase + o] = sval[o]; }
+            // rows keep their index span through the sort (row is the major key)
+            if (tid < nr) c_rowptr[ra + tid] = (int64_t)(obase + sm.rank[sm.rowo[tid]]);
+            if (t + 1 == ntiles && tid == 0) *out_end_p = obase + total;
+        }
         t = tn;
         d = dn;
         __syncthreads();  // LDS is reused by the next tile
@@ -876,7 +887,48 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG>())) vo
     OSP_PROF_FLUSH;
 }
 
-// ---- merge: global-sort path for rows longer than kTileCap ---------------------------------------
+// ---- merge: over-long segments -------------------------------------------------------------------
+// Segments (column ranges of split long rows) that still exceed a tile.  Those up to kBigTileCap entries -- in
+// R-MAT products nearly all of them: the lowest column range of a mid-sized row, where the hub columns sit -- are
+// merged by the SAME tile kernel instantiated with a larger tile (in-place mode, 512 threads); the rest (one output
+// entry fed by many thousands of products) take the global-sort path below.
+constexpr int kBigTileCap = 4096;
+constexpr int kBigTileThreads = 512;
+// list[t] -> huge[scan[t]] or mid[t - scan[t]] by length; scan = exclusive scan of the "huge" flags
+struct SegHugeFlag {
+    const uint32_t *list;
+    const uint64_t *row_off;
+    uint32_t cap;
+    __device__ uint32_t operator()(uint64_t t) const {
+        const uint32_t v = list[t];
+        return (row_off[v + 1] - row_off[v]) > (uint64_t)cap ? 1u : 0u;
+    }
+};
+__global__ void seg_partition_kernel(SegHugeFlag f, const uint32_t *scan, uint32_t n, uint32_t *huge, uint32_t *mid) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    if (f(t)) huge[scan[t]] = f.list[t]; else mid[t - scan[t]] = f.list[t];
+}
+// one in-place tile per mid-sized over-long segment v: key = col - first column of the segment
+__global__ void seg_tile_desc_kernel(const uint32_t *mid, uint32_t nmid, const uint64_t *vrow_off, const uint64_t *vbase,
+                                     const uint8_t *hbits, uint32_t nlong, int colbits, TileDesc *desc) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nmid) return;
+    const uint32_t v = mid[t];
+    const uint32_t h = (uint32_t)(upper_bound_dev(vbase, 0, (uint64_t)nlong + 1, (uint64_t)v) - 1);  // owner long row
+    const int sh = colbits - (int)hbits[h];
+    TileDesc d;
+    d.s = vrow_off[v];
+    d.ra = v;
+    d.nr = 1;
+    d.n = (uint32_t)(vrow_off[v + 1] - vrow_off[v]);
+    d.lvl = 1;
+    d.cbase = (uint32_t)((v - vbase[h]) << sh);
+    d.kbits = (uint32_t)(sh < 1 ? 1 : sh);
+    desc[t] = d;
+}
+
+// ---- merge: global-sort path for segments longer than kBigTileCap --------------------------------
 struct HeavyLen {
     const uint32_t *rows;
     const uint64_t *row_off;
