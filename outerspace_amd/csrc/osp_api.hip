@@ -364,7 +364,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
                 device_exclusive_scan<HeavyLen, uint64_t>(HeavyLen{huge_list, vrow_off}, nhuge, soff, hscan_tmp, s);
                 const uint64_t ns = d2h(soff + nhuge, s);
                 res->info.sorted_partials += ns;
-                uint64_t *keys[2] = {sc.get<uint64_t>(ns), sc.get<uint64_t>(ns)};
+                uint64_t *keys[2] = {sc.get<uint64_t>(ns + 1), sc.get<uint64_t>(ns + 1)};  // +1: the idle one holds the run heads later
                 uint32_t *poss[2] = {sc.get<uint32_t>(ns), sc.get<uint32_t>(ns)};
                 uint32_t *hist = sc.get<uint32_t>(sort_hist_entries(ns));
                 uint32_t *hist_tmp = sc.get<uint32_t>(scan_scratch_entries(sort_hist_entries(ns)));
@@ -376,8 +376,10 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
                 uint64_t *headscan = sc.get<uint64_t>(ns + 1);
                 uint64_t *headscan_tmp = sc.get<uint64_t>(scan_scratch_entries(ns));
                 device_exclusive_scan<HeavyHeadFlag, uint64_t>(HeavyHeadFlag{keys[cur]}, ns, headscan, headscan_tmp, s);
-                heavy_reduce_kernel<T><<<grid_for(ns, 256), 256, 0, s>>>(keys[cur], sorted_val, headscan, ns, huge_list, soff, nhuge,
-                                                                         vrow_off, 0, colbits, qstage);
+                uint64_t *head_pos = keys[cur ^ 1];  // the idle key buffer: one entry per run and a sentinel, <= ns + 1
+                heavy_heads_kernel<<<grid_for(ns + 1, 256), 256, 0, s>>>(keys[cur], headscan, ns, head_pos);
+                heavy_reduce_kernel<T><<<grid_for(ns, 256), 256, 0, s>>>(keys[cur], sorted_val, headscan, head_pos, ns, huge_list, soff,
+                                                                         nhuge, vrow_off, 0, colbits, qstage);
                 heavy_rows_kernel<<<grid_for(nhuge, 256), 256, 0, s>>>(huge_list, soff, nhuge, headscan, seg_nnz);
             }
             heavy_src_inplace_kernel<<<grid_for(nseg_long, 256), 256, 0, s>>>(p1.long_rows, nseg_long, vrow_off, 0, seg_src);

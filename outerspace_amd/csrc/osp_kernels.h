@@ -954,20 +954,55 @@ __global__ void heavy_gather_kernel(const uint32_t *pos, const Part<T> *stage, u
     uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x < nh) sorted_val[x] = stage[pos[x]].val;
 }
-// every run head sums its run (ascending staging position = ascending k) and writes in place
+// head_pos[r] = first sorted position of run r (r = headscan at a head); head_pos[number of runs] = nh
+__global__ void heavy_heads_kernel(const uint64_t *key, const uint64_t *headscan, uint64_t nh, uint64_t *head_pos) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x > nh) return;
+    if (x == nh) { head_pos[headscan[nh]] = nh; return; }
+    if (x == 0 || key[x] != key[x - 1]) head_pos[headscan[x]] = x;
+}
+// One thread per run of equal (segment, col) keys: the run is summed in sorted order (= ascending staging position
+// = ascending k) and written in place.  Short runs are summed by their own thread; a run of more than 64 entries --
+// a pile: one output entry fed by thousands of products -- is summed by the whole wave: 64 values per coalesced load,
+// added one after the other in the same order (v_readlane), so the result does not change, only the memory access.
 template <class T>
-__global__ void heavy_reduce_kernel(const uint64_t *key, const T *sorted_val, const uint64_t *headscan,
-                                    uint64_t nh, const uint32_t *rows, const uint64_t *hoff,
-                                    uint32_t nheavy, const uint64_t *row_off, uint64_t base,
-                                    int colbits, Part<T> *stage) {
-    uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= nh) return;
-    const uint64_t k = key[x];
-    if (x != 0 && key[x - 1] == k) return;
-    T acc = sorted_val[x];
-    for (uint64_t u = x + 1; u < nh && key[u] == k; u++) acc += sorted_val[u];
+__global__ __launch_bounds__(256) void heavy_reduce_kernel(const uint64_t *key, const T *sorted_val, const uint64_t *headscan,
+                                                           const uint64_t *head_pos, uint64_t nh, const uint32_t *rows,
+                                                           const uint64_t *hoff, uint32_t nheavy, const uint64_t *row_off,
+                                                           uint64_t base, int colbits, Part<T> *stage) {
+    constexpr uint64_t kWaveRun = 64;
+    const uint64_t nruns = headscan[nh];
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned lane = lane_id();
+    const bool mine = r < nruns;
+    uint64_t a = 0, e = 0;
+    if (mine) { a = head_pos[r]; e = head_pos[r + 1]; }
+    T acc = 0;
+    const bool lng = mine && (e - a) > kWaveRun;
+    if (mine && !lng) {
+        acc = sorted_val[a];
+        for (uint64_t u = a + 1; u < e; u++) acc += sorted_val[u];
+    }
+    uint64_t m = __ballot(lng);
+    while (m) {
+        const uint32_t j = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1;
+        const uint64_t ja = wave_bcast(a, j), je = wave_bcast(e, j);
+        T sum = 0;
+        for (uint64_t b0 = ja; b0 < je; b0 += kWave) {
+            const uint64_t x = b0 + lane;
+            const T v = x < je ? sorted_val[x] : (T)0;
+            const uint32_t cnt = (uint32_t)min((uint64_t)kWave, je - b0);
+            uint32_t t0 = 0;
+            if (b0 == ja) { sum = wave_bcast(v, 0u); t0 = 1; }  // the sum starts AS the first entry (keeps a lone -0.0)
+            for (uint32_t t = t0; t < cnt; t++) sum += wave_bcast(v, t);
+        }
+        if (lane == j) acc = sum;
+    }
+    if (!mine) return;
+    const uint64_t k = key[a];
     const uint64_t h = k >> colbits;
-    const uint64_t o = row_off[rows[h]] - base + (headscan[x] - headscan[hoff[h]]);
+    const uint64_t o = row_off[rows[h]] - base + (r - headscan[hoff[h]]);
     stage[o] = Part<T>{(uint32_t)(k & ((1ull << colbits) - 1ull)), acc};
 }
 __global__ void heavy_rows_kernel(const uint32_t *rows, const uint64_t *hoff, uint32_t nheavy,
