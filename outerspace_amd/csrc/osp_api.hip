@@ -342,8 +342,9 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
             lv.heavy_nnz[1] = seg_nnz;
             // by length: up to kBigTileCap -> one big LDS tile each, reduced in place; beyond -> global sort
             uint32_t *hscan = sc.get<uint32_t>((uint64_t)nseg_long + 1);
+            uint64_t *sscan_tmp = sc.get<uint64_t>(scan_scratch_entries(nseg_long));  // NOT hscan_tmp: that one is sized for nlong
             const SegHugeFlag hf{p1.long_rows, vrow_off, (uint32_t)kBigTileCap};
-            device_exclusive_scan<SegHugeFlag, uint32_t>(hf, nseg_long, hscan, (uint32_t *)hscan_tmp, s);
+            device_exclusive_scan<SegHugeFlag, uint32_t>(hf, nseg_long, hscan, (uint32_t *)sscan_tmp, s);
             const uint32_t nhuge = d2h(hscan + nseg_long, s), nmid = nseg_long - nhuge;
             uint32_t *huge_list = sc.get<uint32_t>(nhuge), *mid_list = sc.get<uint32_t>(nmid);
             seg_partition_kernel<<<grid_for(nseg_long, 256), 256, 0, s>>>(hf, hscan, nseg_long, huge_list, mid_list);
@@ -361,7 +362,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
                 // one output entry fed by more products than any tile holds: global stable sort on (segment, col),
                 // run sums in place in the second buffer
                 uint64_t *soff = sc.get<uint64_t>((uint64_t)nhuge + 1);
-                device_exclusive_scan<HeavyLen, uint64_t>(HeavyLen{huge_list, vrow_off}, nhuge, soff, hscan_tmp, s);
+                device_exclusive_scan<HeavyLen, uint64_t>(HeavyLen{huge_list, vrow_off}, nhuge, soff, sscan_tmp, s);
                 const uint64_t ns = d2h(soff + nhuge, s);
                 res->info.sorted_partials += ns;
                 uint64_t *keys[2] = {sc.get<uint64_t>(ns + 1), sc.get<uint64_t>(ns + 1)};  // +1: the idle one holds the run heads later

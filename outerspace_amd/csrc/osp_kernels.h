@@ -22,7 +22,7 @@ namespace osp {
 // LDS.  (Measured, tools/bench_merge: four independent barrier domains per CU beat two workgroups of 512 threads
 // on tiles twice as large -- 3.5 vs 4.0 ms for 2.7e8 partial products -- although every tile costs a look-back.)
 template <class T> struct TileCap;
-template <> struct TileCap<float> { static constexpr int value = 1792; };
+template <> struct TileCap<float> { static constexpr int value = 1536; };
 template <> struct TileCap<double> { static constexpr int value = 1536; };
 constexpr int kMergeThreads = 256;
 constexpr int kTileMaxRows = kMergeThreads - 1;  // rows per tile: 8 row bits in the sort key, one row offset per thread

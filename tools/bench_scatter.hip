@@ -18,6 +18,29 @@ __device__ inline uint64_t slot_of(uint64_t c, uint64_t nch) {
     return win | (((c * 0x9E3779B1ull) ^ 0x5bd1e995ull) & (wch - 1));
 }
 
+// MODE 2: the same AoS bytes, written as single dwords (lane -> dword of the chunk's byte range): 3 store
+// instructions of one dword per lane instead of one of three dwords per lane
+__global__ void scatter_dwords_kernel(Rec *rec, uint64_t nch, int clen, int shift) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = 64 / clen;
+    const uint64_t wave = gid >> 6; const int lane = gid & 63;
+    uint32_t *out = (uint32_t *)rec;
+    for (int it = 0; it < 8; it++) {
+        const uint64_t c0 = (wave * 8 + it) * per;
+        for (int q = 0; q < 3; q++) {
+            const int g = q * 64 + lane;
+            const int jj = g / (3 * clen), w = g % (3 * clen);
+            const uint64_t c = c0 + jj;
+            if (c >= nch) continue;
+            const uint64_t dst = (slot_of(c, nch) * clen + shift) * 3 + w;   // dword index
+            const int l = w / 3, comp = w % 3;
+            const double v = (double)l;
+            const uint32_t word = comp == 0 ? (uint32_t)c : comp == 1 ? (uint32_t)__double_as_longlong(v) : (uint32_t)(__double_as_longlong(v) >> 32);
+            out[dst] = word;
+        }
+    }
+}
+
 template <int MODE>  // 0 SoA, 1 AoS
 __global__ void scatter_kernel(uint32_t *pcol, double *pval, Rec *rec, uint64_t nch, int clen, int shift) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -46,18 +69,19 @@ int main(int argc, char **argv) {
     uint64_t wch = 1; while (wch * 2 * clen * 12 <= wmb * 1024 * 1024 && wch * 2 <= nch) wch *= 2;
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_wch), &wch, 8));
     printf("-- window %llu chunks = %.0f MB of staging\n", (unsigned long long)wch, wch * clen * 12.0 / 1048576);
-    for (int shift : {0, 5}) for (int mode : {0, 1}) {
+    for (int shift : {0, 5}) for (int mode : {0, 1, 2}) {
         std::vector<float> t;
         for (int r = 0; r < 4; r++) {
             hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
             CK(hipEventRecord(a, 0));
             if (mode == 0) scatter_kernel<0><<<grid, 256>>>(pcol, pval, rec, nch, clen, shift);
-            else scatter_kernel<1><<<grid, 256>>>(pcol, pval, rec, nch, clen, shift);
+            else if (mode == 1) scatter_kernel<1><<<grid, 256>>>(pcol, pval, rec, nch, clen, shift);
+            else scatter_dwords_kernel<<<grid, 256>>>(rec, nch, clen, shift);
             CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
             float ms; CK(hipEventElapsedTime(&ms, a, b)); t.push_back(ms);
         }
         std::sort(t.begin(), t.end());
-        printf("clen %d shift %d %s: %.3f ms  %.1f GB/s\n", clen, shift, mode ? "AoS" : "SoA", t[1], 12.0 * nch * clen / (t[1] * 1e-3) / 1e9);
+        printf("clen %d shift %d %s: %.3f ms  %.1f GB/s\n", clen, shift, mode == 0 ? "SoA" : mode == 1 ? "AoS x3" : "AoS dwords", t[1], 12.0 * nch * clen / (t[1] * 1e-3) / 1e9);
     }
     }
     return 0;
