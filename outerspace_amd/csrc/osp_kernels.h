@@ -18,9 +18,10 @@
 namespace osp {
 
 // ---- tunables --------------------------------------------------------------------------------
-// partial products one LDS merge tile holds: sized so that FOUR workgroups of 256 threads fit the CU's 160 KiB
-// LDS.  (Measured, tools/bench_merge: four independent barrier domains per CU beat two workgroups of 512 threads
-// on tiles twice as large -- 3.5 vs 4.0 ms for 2.7e8 partial products -- although every tile costs a look-back.)
+// partial products one LDS merge tile holds.  Six per thread of a 256-thread workgroup: the kernel then needs 96
+// registers, so FIVE workgroups run per CU (31 KB of LDS each).  (Measured, tools/bench_merge, 2.7e8 partial
+// products: two workgroups of 512 threads on 3072-entry tiles 4.0 ms, four of 256 on 1536 3.5 ms, five 3.3 ms --
+// independent barrier domains per CU matter more than tile size, although every tile costs a look-back.)
 template <class T> struct TileCap;
 template <> struct TileCap<float> { static constexpr int value = 1536; };
 template <> struct TileCap<double> { static constexpr int value = 1536; };
