@@ -702,6 +702,58 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         if (space == OSP_HOST) { e0 = a_colptr_in[k0]; e1 = a_colptr_in[k1]; }
         else { e0 = d2h(a_colptr + k0, s); e1 = d2h(a_colptr + k1, s); }
     }
+    // ---- row-sharded multi-GPU mode: find this rank's rows and drop the rest of A BEFORE the symbolic phase ----
+    // (a rank then sorts 1/G of A's non-zeros instead of all of them; every rank derives the same bounds from the
+    // replicated operands alone: no collective)
+    uint64_t r_lo = 0, r_hi = M;
+    const bool row_sharded = cfg.row_shard_count > 1;
+    if (row_sharded) {
+        const uint64_t nnz = (uint64_t)(e1 - e0);  // all of the k shard's non-zeros: the pre-pass sees every row
+        if (cfg.row_shard_index < 0 || cfg.row_shard_index >= cfg.row_shard_count) throw Error(OSP_ERR_ARG, "row shard index out of range");
+        const uint32_t G = (uint32_t)cfg.row_shard_count;
+        tm.begin(PH_SYM);
+        {
+            Scratch cs(ctx);
+            unsigned long long *work = (unsigned long long *)cs.get<uint64_t>(M + 1);
+            uint64_t *pre = cs.get<uint64_t>(M + 1), *cost_pre = cs.get<uint64_t>(M + 1);
+            uint64_t *tmp = cs.get<uint64_t>(scan_scratch_entries(M + 1));
+            uint64_t *d_b = cs.get<uint64_t>(2ull * (G + 1));
+            OSP_HIP(hipMemsetAsync(work, 0, (M + 1) * sizeof(uint64_t), s));
+            // every 16th column is sample enough to balance G shards of a large matrix; small ones are counted exactly
+            const uint32_t stride = (k1 - k0) >= (1u << 16) ? 16u : 1u;
+            const uint64_t nsample = (k1 - k0 + stride - 1) / stride;
+            if (nnz) row_work_kernel<<<grid_for(nsample * kWave, 256), 256, 0, s>>>(a_colptr, a_rowidx, b_rowptr, k0, k1, stride, work);
+            device_exclusive_scan<LoadU64, uint64_t>(LoadU64{(const uint64_t *)work}, M, pre, tmp, s);
+            device_exclusive_scan<RowCost, uint64_t>(RowCost{pre, (uint64_t)TileCap<T>::value, kSplitRowMax}, M, cost_pre, tmp, s);
+            shard_bounds_kernel<<<grid_for(G + 1, 64), 64, 0, s>>>(cost_pre, pre, M, G, d_b, d_b + G + 1);
+            std::vector<uint64_t> h_b(2ull * (G + 1));
+            OSP_HIP(hipMemcpyAsync(h_b.data(), d_b, h_b.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            OSP_HIP(hipStreamSynchronize(s));
+            r_lo = h_b[cfg.row_shard_index];
+            r_hi = h_b[cfg.row_shard_index + 1];
+        }
+        // A restricted to rows [r_lo, r_hi): same K columns, absolute row ids
+        int64_t *colptr2 = sc.get<int64_t>(K + 1);
+        uint64_t nnz2 = 0;
+        uint32_t *rowidx2 = nullptr;
+        T *vals2 = nullptr;
+        {
+            Scratch cs(ctx);
+            uint32_t *keep_scan = cs.get<uint32_t>(nnz + 1);
+            uint32_t *tmp = cs.get<uint32_t>(scan_scratch_entries(nnz + 1));
+            const RowInRange keep{a_rowidx + e0, (uint32_t)r_lo, r_hi};
+            device_exclusive_scan<RowInRange, uint32_t>(keep, nnz, keep_scan, tmp, s);
+            nnz2 = d2h(keep_scan + nnz, s);
+            rowidx2 = sc.get<uint32_t>(nnz2);
+            vals2 = sc.get<T>(nnz2);
+            restrict_colptr_kernel<<<grid_for(K + 1, 256), 256, 0, s>>>(a_colptr, K, e0, nnz, keep_scan, colptr2);
+            if (nnz2) restrict_compact_kernel<T><<<grid_for(nnz, 256), 256, 0, s>>>(keep, keep_scan, nnz, a_vals + e0, rowidx2, vals2);
+        }
+        tm.end(PH_SYM);
+        a_colptr = colptr2; a_rowidx = rowidx2; a_vals = vals2;
+        e0 = 0;  // columns before k0 are empty now
+        e1 = (int64_t)nnz2;
+    }
     const uint64_t nnz = (uint64_t)(e1 - e0);  // non-zeros of A inside the shard
 
     // ---- symbolic: chunk offsets in (row, k) order ----
@@ -754,22 +806,8 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     prod.prod = sc.get<uint64_t>(nk); prod.prod_off = sc.get<uint64_t>(nk + 1);
     prod.scan_tmp = sc.get<uint64_t>(scan_scratch_entries(nk));
 
-    uint64_t r_lo = 0, r_hi = M, off_lo = 0, P_rows = P;
-    if (cfg.row_shard_count > 1) {
-        // row-sharded multi-GPU mode: this rank's contiguous range of output rows, balanced by partial products
-        if (cfg.row_shard_index < 0 || cfg.row_shard_index >= cfg.row_shard_count) throw Error(OSP_ERR_ARG, "row shard index out of range");
-        const uint32_t G = (uint32_t)cfg.row_shard_count;
-        uint64_t *d_b = sc.get<uint64_t>(2ull * (G + 1));
-        shard_bounds_kernel<<<grid_for(G + 1, 64), 64, 0, s>>>(row_off, M, P, G, d_b, d_b + G + 1);
-        std::vector<uint64_t> h_b(2ull * (G + 1));
-        OSP_HIP(hipMemcpyAsync(h_b.data(), d_b, h_b.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-        OSP_HIP(hipStreamSynchronize(s));
-        r_lo = h_b[cfg.row_shard_index];
-        r_hi = h_b[cfg.row_shard_index + 1];
-        off_lo = h_b[G + 1 + cfg.row_shard_index];
-        P_rows = h_b[G + 1 + cfg.row_shard_index + 1] - off_lo;
-        res->info.partials = P_rows;
-    }
+    // row-sharded: A holds this rank's rows only, so the staging offsets start at 0 at r_lo and P is the shard's count
+    const uint64_t off_lo = 0, P_rows = P;
     merge_pipeline<T>(ctx, res, prod, M, N, row_off, arow, chunk_start, P_rows, cfg.partial_capacity, tm, r_lo, r_hi, off_lo, sink);
 
     OSP_HIP(hipEventRecord(ev1, s));

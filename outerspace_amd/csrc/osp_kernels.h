@@ -1039,17 +1039,75 @@ struct RowUpperBound {
     uint64_t N;
     __device__ uint64_t operator()(uint64_t r) const { return min(row_off[r + 1] - row_off[r], N); }
 };
-// bounds[j] = first row whose staging offset reaches j/G of all partial products (j = 0..G): row ranges of
-// equal work that every rank computes identically from the operands alone
-__global__ void shard_bounds_kernel(const uint64_t *row_off, uint64_t M, uint64_t P, uint32_t G, uint64_t *bounds, uint64_t *offs) {
+// Estimated cost of row r, in sixteenths of "one partial product of a short row": a row that fits a tile costs
+// multiply + merge; a long row also pays the column-range split (x1.6), a row beyond the one-workgroup split the
+// two-pass stretch split (x2.5, which also absorbs what else is slower about hub rows).  (Fitted to the per-shard times of tools/shard_balance.py on R-MAT-22 mild: 18,
+// 29 and 35 ps per partial product.)  Only the balance of the row shards depends on it, never a result.
+struct RowCost {
+    const uint64_t *row_off;
+    uint64_t cap, one_wg_max;
+    __device__ uint64_t operator()(uint64_t r) const {
+        const uint64_t u = row_off[r + 1] - row_off[r];
+        return u * (u <= cap ? 16u : u <= one_wg_max ? 26u : 40u);
+    }
+};
+// bounds[j] = first row whose cost prefix reaches j/G of the total (j = 0..G): row ranges of equal estimated work
+// that every rank computes identically from the operands alone; offs[j] = staging offset of that row
+__global__ void shard_bounds_kernel(const uint64_t *cost_pre, const uint64_t *row_off, uint64_t M, uint32_t G, uint64_t *bounds,
+                                    uint64_t *offs) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > G) return;
-    uint64_t r = j == G ? M : lower_bound_dev(row_off, 0, M + 1, (uint64_t)((unsigned __int128)P * j / G));
+    const uint64_t total = cost_pre[M];
+    uint64_t r = j == G ? M : lower_bound_dev(cost_pre, 0, M + 1, (uint64_t)((unsigned __int128)total * j / G));
     if (r > M) r = M;
     bounds[j] = r;
     offs[j] = row_off[r];
 }
 __global__ void set_u64_kernel(uint64_t *p, uint64_t v) { *p = v; }
+
+// ---- row-sharded mode: this rank's rows only, before the symbolic phase ---------------------------------------
+// work[r] += stride * nnz(B[k,:]) for the non-zeros A[r,k] of every stride-th column of the k shard: an estimate of
+// each row's partial products from a deterministic sample of the columns (integer atomics: order-free, so every rank
+// gets the same numbers).  One wave per sampled column.  Only the BALANCE of the row shards depends on the estimate.
+__global__ void row_work_kernel(const int64_t *a_colptr, const uint32_t *a_rowidx, const int64_t *b_rowptr, uint64_t k0,
+                                uint64_t k1, uint32_t stride, unsigned long long *work) {
+    const uint64_t wv = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t k = k0 + wv * stride;
+    if (k >= k1) return;
+    const unsigned long long w = (unsigned long long)(b_rowptr[k + 1] - b_rowptr[k]) * stride;
+    if (!w) return;
+    const int64_t lo = a_colptr[k], hi = a_colptr[k + 1];
+    for (int64_t e = lo + lane_id(); e < hi; e += kWave) atomicAdd(&work[a_rowidx[e]], w);
+}
+// A restricted to rows [r0, r1) by stream compaction of its non-zeros (CSC order is kept, so it stays a CSC):
+// keep[t] flags, their exclusive scan = new positions; the new column pointers are the scan read at the old ones
+struct RowInRange {
+    const uint32_t *rows;  // already offset to the k shard's first non-zero
+    uint32_t r0;
+    uint64_t r1;
+    __device__ uint32_t operator()(uint64_t t) const { const uint32_t r = rows[t]; return (r >= r0 && (uint64_t)r < r1) ? 1u : 0u; }
+};
+__global__ void restrict_colptr_kernel(const int64_t *a_colptr, uint64_t K, int64_t e0, uint64_t nnz, const uint32_t *keep_scan,
+                                       int64_t *colptr2) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > K) return;
+    int64_t t = a_colptr[k] - e0;
+    t = t < 0 ? 0 : (t > (int64_t)nnz ? (int64_t)nnz : t);  // columns outside the k shard become empty
+    colptr2[k] = (int64_t)keep_scan[t];
+}
+template <class T>
+__global__ void restrict_compact_kernel(RowInRange keep, const uint32_t *keep_scan, uint64_t nnz, const T *a_vals, uint32_t *rowidx2,
+                                        T *vals2) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nnz || !keep(t)) return;
+    const uint32_t j = keep_scan[t];
+    rowidx2[j] = keep.rows[t];
+    vals2[j] = a_vals[t];
+}
+struct LoadU64AsI64 {
+    const uint64_t *p;
+    __device__ int64_t operator()(uint64_t i) const { return (int64_t)p[i]; }
+};
 
 // ---- CSR parts -> staging (multi-GPU final merge) ----------------------------------
 // Row r of part p becomes one chunk of row r; chunks ordered by p.

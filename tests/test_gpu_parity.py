@@ -427,7 +427,7 @@ def test_device_ingest_coo(ctx, port):
 
 def test_row_shards_tile_the_product(ctx, port):
     """Row-sharded multi-GPU mode: G results with disjoint, contiguous row ranges that concatenate to the full CSR
-    (bit-exact), ranges balanced by partial products and derived identically by every rank."""
+    (bit-exact), ranges balanced by estimated work and derived identically by every rank."""
     n, rows, cols, vals = gen.rmat_coo(13, 12, "mild", seed=8)
     got_full, want = run_both(ctx, port, n, n, n, (rows, cols, vals), (rows, cols, vals), np.float64)
     from outerspace_amd import spgemm as S
@@ -441,7 +441,7 @@ def test_row_shards_tile_the_product(ctx, port):
             lo, hi = want["rowptr"][r0], want["rowptr"][r1]
             assert np.array_equal(r.rowptr, want["rowptr"][r0:r1 + 1] - lo)
             assert np.array_equal(r.colidx, want["colidx"][lo:hi]) and np.array_equal(r.vals, want["vals"][lo:hi])
-            assert r.info["partials"] <= want["partials"] / G * 1.5 + 5000  # balanced by work
+            assert r.info["partials"] <= want["partials"] / G * 2.0 + 5000  # balanced by estimated work (long rows weigh more)
             end, P = r1, P + r.info["partials"]
         assert end == n and P == want["partials"]
 
