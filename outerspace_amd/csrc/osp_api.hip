@@ -18,7 +18,6 @@
 #include "../../include/outerspace_spgemm.h"
 #include "osp_internal.h"
 #include "osp_kernels.h"
-#include "osp_merge_runs.h"
 #include "osp_split.h"
 #include "osp_sort.h"
 
@@ -431,7 +430,7 @@ struct PanelSink {
 // ---- stages shared by both entry points: partial products of each row -> final CSR ----------------
 template <class T>
 static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_t M_all, uint64_t N,
-                           const uint64_t *d_row_off, const uint32_t *d_arow, const uint64_t *d_chunk_start,
+                           const uint64_t *d_row_off,
                            uint64_t P, uint64_t cap_cfg, PhaseTimer &tm, uint64_t r_lo = 0, uint64_t r_hi = ~0ull,
                            uint64_t off_lo = 0, const PanelSink *sink = nullptr) {
     // output rows [r_lo, r_hi) only (row-sharded multi-GPU mode); P = their partial products, off_lo = row_off[r_lo]
@@ -442,9 +441,8 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     res->info.row_end = r_hi;
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
-    // merge algorithm of the LDS tiles: stable 9-bit LSD radix sort (default) or pairwise merging of the
-    // pre-sorted chunks (osp_merge_runs.h).  Measured on MI355X with tools/bench_merge: radix 4.95 ms vs
-    // runs 6.9 ms per 2.7e8 partial products (16 chunks of 16 per row), so radix is what ships.
+    // (The LDS tiles are merged by a stable LSD radix sort; pairwise merging of the pre-sorted chunks was built and
+    // measured slower -- osp_merge_runs.h, tools/bench_merge -- and is not wired into the library.)
     const int colbits = std::max(1, bits_for(N));
 
     if (!sink) res->rowptr = (int64_t *)ctx->alloc((M + 1) * sizeof(int64_t));
@@ -759,14 +757,10 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     // ---- symbolic: chunk offsets in (row, k) order ----
     tm.begin(PH_SYM);
     uint64_t *row_off = sc.get<uint64_t>(M + 1);
-    uint32_t *arow = sc.get<uint32_t>(M + 1);
     uint64_t *chunk_off = sc.get<uint64_t>(nnz);
-    uint64_t *chunk_start = sc.get<uint64_t>(nnz + 1);  // non-empty chunks, (row, k) order
     uint64_t P = 0;
     if (nnz == 0) {
         OSP_HIP(hipMemsetAsync(row_off, 0, (M + 1) * sizeof(uint64_t), s));
-        OSP_HIP(hipMemsetAsync(arow, 0, (M + 1) * sizeof(uint32_t), s));
-        OSP_HIP(hipMemsetAsync(chunk_start, 0, sizeof(uint64_t), s));
     } else {
         Scratch ss(ctx);
         uint32_t *ka = ss.get<uint32_t>(nnz), *pa = ss.get<uint32_t>(nnz), *kb = ss.get<uint32_t>(nnz), *pb = ss.get<uint32_t>(nnz);
@@ -774,7 +768,6 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         uint32_t *hist = ss.get<uint32_t>(rs_hist_entries(nnz));
         uint32_t *hist_tmp = ss.get<uint32_t>(scan_scratch_entries(rs_hist_entries(nnz)));
         uint64_t *offs_sorted = ss.get<uint64_t>(nnz + 1);
-        uint32_t *ne_scan = ss.get<uint32_t>(nnz + 1);
         uint64_t *scan_tmp = ss.get<uint64_t>(scan_scratch_entries(nnz));
         // (row, k) order of A's non-zeros; the last sort pass also looks up each chunk's length
         uint32_t *w = ss.get<uint32_t>(nnz);
@@ -782,15 +775,8 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         device_sort_rows<SymEpilogue>(a_rowidx + e0, nnz, std::max(1, bits_for(M)), ka, pa, kb, pb, hist, hist_tmp,
                                       SymEpilogue{w, rows_sorted, perm, w_sorted}, s);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{w_sorted}, nnz, offs_sorted, scan_tmp, s);
-        if (kMergeByRuns) {
-            const NonEmptyFlag<LoadU32> nef{LoadU32{w_sorted}};
-            device_exclusive_scan<NonEmptyFlag<LoadU32>, uint32_t>(nef, nnz, ne_scan, (uint32_t *)scan_tmp, s);
-            chunk_compact_kernel<LoadU32><<<grid_for(nnz + 1, 256), 256, 0, s>>>(LoadU32{w_sorted}, offs_sorted, ne_scan, nnz,
-                                                                                chunk_start);
-        }
         sym_scatter_offsets_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(perm, offs_sorted, nnz, chunk_off);
-        sym_row_offsets_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(rows_sorted, offs_sorted, kMergeByRuns ? ne_scan : nullptr,
-                                                                    nnz, M, row_off, arow);
+        sym_row_offsets_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(rows_sorted, offs_sorted, nnz, M, row_off);
         P = d2h(offs_sorted + nnz, s);
     }
     tm.end(PH_SYM);
@@ -808,7 +794,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
 
     // row-sharded: A holds this rank's rows only, so the staging offsets start at 0 at r_lo and P is the shard's count
     const uint64_t off_lo = 0, P_rows = P;
-    merge_pipeline<T>(ctx, res, prod, M, N, row_off, arow, chunk_start, P_rows, cfg.partial_capacity, tm, r_lo, r_hi, off_lo, sink);
+    merge_pipeline<T>(ctx, res, prod, M, N, row_off, P_rows, cfg.partial_capacity, tm, r_lo, r_hi, off_lo, sink);
 
     OSP_HIP(hipEventRecord(ev1, s));
     OSP_HIP(hipStreamSynchronize(s));
@@ -924,26 +910,18 @@ static void merge_parts_impl(Context *ctx, Result *res, uint64_t M, uint64_t N, 
     tm.begin(PH_SYM);
     const uint64_t ncand = M * (uint64_t)nparts;  // candidate chunk (r, p) = row r of part p
     uint64_t *row_off = sc.get<uint64_t>(M + 1);
-    uint32_t *arow = sc.get<uint32_t>(M + 1);
     uint64_t *offs = sc.get<uint64_t>(ncand + 1);
-    uint32_t *ne_scan = sc.get<uint32_t>(ncand + 1);
-    uint64_t *chunk_start = sc.get<uint64_t>(ncand + 1);
     uint64_t *scan_tmp = sc.get<uint64_t>(scan_scratch_entries(ncand));
     const PartsChunkLen plen{d_rp, nparts};
     device_exclusive_scan<PartsChunkLen, uint64_t>(plen, ncand, offs, scan_tmp, s);
-    if (kMergeByRuns) {
-        device_exclusive_scan<NonEmptyFlag<PartsChunkLen>, uint32_t>(NonEmptyFlag<PartsChunkLen>{plen}, ncand, ne_scan,
-                                                                     (uint32_t *)scan_tmp, s);
-        chunk_compact_kernel<PartsChunkLen><<<grid_for(ncand + 1, 256), 256, 0, s>>>(plen, offs, ne_scan, ncand, chunk_start);
-    }
-    parts_rows_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(offs, kMergeByRuns ? ne_scan : nullptr, nparts, M, row_off, arow);
+    parts_rows_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(offs, nparts, M, row_off);
     const uint64_t P = d2h(offs + ncand, s);
     tm.end(PH_SYM);
     res->info.partials = P;
     PartsProducer<T> prod;
     prod.ctx = ctx; prod.d_rowptrs = d_rp; prod.d_colidxs = d_ci; prod.d_valss = d_va;
     prod.nparts = nparts; prod.row_off = row_off;
-    merge_pipeline<T>(ctx, res, prod, M, N, row_off, arow, chunk_start, P, cfg.partial_capacity, tm);
+    merge_pipeline<T>(ctx, res, prod, M, N, row_off, P, cfg.partial_capacity, tm);
     OSP_HIP(hipEventRecord(ev1, s));
     OSP_HIP(hipStreamSynchronize(s));
     float ms = 0;

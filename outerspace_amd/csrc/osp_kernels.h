@@ -28,7 +28,6 @@ template <> struct TileCap<double> { static constexpr int value = 1536; };
 constexpr int kMergeThreads = 256;
 constexpr int kTileMaxRows = kMergeThreads - 1;  // rows per tile: 8 row bits in the sort key, one row offset per thread
 constexpr int kMulThreads = 256;
-constexpr bool kMergeByRuns = false;  // see merge_pipeline() in osp_api.hip
 constexpr int kMulPerWave = 2048;  // partial products per wave slice
 constexpr int kMulPerBlock = kMulPerWave * (kMulThreads / kWave);
 
@@ -138,14 +137,12 @@ __global__ void sym_scatter_offsets_kernel(const uint32_t *perm, const uint64_t 
 
 // row_off[i] = staging offset of row i's first partial product, arow[i] = index of its first
 // non-empty chunk, i in [0, M]
-__global__ void sym_row_offsets_kernel(const uint32_t *rows_sorted, const uint64_t *offs_sorted,
-                                       const uint32_t *nonempty_scan, uint64_t nnz, uint64_t M,
-                                       uint64_t *row_off, uint32_t *arow) {
+__global__ void sym_row_offsets_kernel(const uint32_t *rows_sorted, const uint64_t *offs_sorted, uint64_t nnz, uint64_t M,
+                                       uint64_t *row_off) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > M) return;
     uint64_t t = lower_bound_dev(rows_sorted, 0, nnz, (uint64_t)i);
     row_off[i] = offs_sorted[t];  // offs_sorted has nnz+1 entries, [nnz] = P
-    if (nonempty_scan) arow[i] = nonempty_scan[t];
 }
 struct LenGatherW {  // chunk length of the t-th A entry in (row, k) order
     const uint32_t *w;
@@ -1120,12 +1117,10 @@ struct PartsChunkLen {  // candidate chunk c = r * nparts + p
         return (uint64_t)(rowptrs[p][r + 1] - rowptrs[p][r]);
     }
 };
-__global__ void parts_rows_kernel(const uint64_t *offs, const uint32_t *flscan, int nparts, uint64_t M,
-                                  uint64_t *row_off, uint32_t *arow) {
+__global__ void parts_rows_kernel(const uint64_t *offs, int nparts, uint64_t M, uint64_t *row_off) {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > M) return;
     row_off[r] = offs[r * (uint64_t)nparts];
-    if (flscan) arow[r] = flscan[r * (uint64_t)nparts];
 }
 template <class T>
 __global__ void parts_scatter_kernel(const int64_t *const *rowptrs, const uint32_t *const *colidxs,

@@ -256,14 +256,4 @@ __global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
         // (the zeroing of cnt at the top of the next round touches the same d from the same thread)
     }
 }
-// merged long row h: its entry count and where it sits in the temporary output
-__global__ void split_rows_done_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *vbase, const int64_t *vptr,
-                                       uint32_t *heavy_nnz, uint64_t *heavy_src) {
-    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= nheavy) return;
-    const int64_t a = vptr[vbase[h]], b = vptr[vbase[h + 1]];
-    heavy_nnz[rows[h]] = (uint32_t)(b - a);
-    heavy_src[h] = (uint64_t)a;
-}
-
 }  // namespace osp
