@@ -1,0 +1,97 @@
+"""Randomised differential test: the HIP path against the CPU oracle on shapes, densities and skews drawn at
+random (seeded), through the code paths a fixed test list never combines: panels of random capacity, row shards,
+k ranges, streamed panels, both value types, both long-row split kernels.  Everything bit-exact."""
+import numpy as np
+import pytest
+
+from outerspace_amd import generators as gen
+
+pytestmark = pytest.mark.gpu
+SEEN = {"cases": 0, "long_rows": 0, "piles": 0, "panels": 0}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from outerspace_amd import spgemm as S
+    c = S.Context(0)
+    yield c
+    c.close()
+
+
+def skewed_coo(rng, nrow, ncol, nnz, alpha, dtype):
+    """nnz distinct coordinates; row and column ids drawn from a power law (alpha = 0: uniform) so that a few rows /
+    columns are hubs -- long rows, over-long segments and piles all appear at small sizes."""
+    def draw(n, size):
+        if alpha == 0:
+            return rng.integers(0, n, size)
+        u = rng.random(size)
+        return np.minimum((n * u ** (1.0 + alpha)).astype(np.int64), n - 1)
+    r, c = draw(nrow, nnz * 2), draw(ncol, nnz * 2)
+    key = np.unique(r * ncol + c)
+    if len(key) > nnz:
+        key = rng.choice(key, nnz, replace=False)
+        key.sort()
+    vals = rng.uniform(-1.5, 1.5, len(key)).astype(dtype)
+    return (key // ncol).astype(np.uint32), (key % ncol).astype(np.uint32), vals
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_products_match_the_oracle(ctx, port, monkeypatch, seed):
+    from outerspace_amd import spgemm as S
+    rng = np.random.default_rng(1000 + seed)
+    dt = np.float64 if seed % 3 else np.float32
+    M, K, N = (int(rng.integers(1, 2500)) for _ in range(3))
+    if seed % 5 == 0:
+        N = int(rng.integers(1, 40))          # narrow output: heavy duplication, piles
+    alpha = float(rng.choice([0.0, 0.5, 1.5, 3.0]))
+    a = skewed_coo(rng, M, K, int(rng.integers(0, 120000)), alpha, dt)
+    b = skewed_coo(rng, K, N, int(rng.integers(0, 120000)), alpha, dt)
+    if seed % 4 == 1:
+        monkeypatch.setenv("OSP_SPLIT_ROW_MAX", str(int(rng.choice([0, 3000, 20000]))))
+    acsc = S.coo_to_csc(K, a[0], a[1], a[2])
+    bcsr = S.coo_to_csr(K, b[0], b[1], b[2])
+    want = port.spgemm(M, K, N, *acsc, *bcsr)
+    P = want["partials"]
+    cap = int(rng.choice([0, max(P // 3, 1), max(P // 9, 1)]))
+    # capacity must hold the longest row
+    rowlen = np.bincount(a[0], weights=np.diff(bcsr[0])[a[1]], minlength=M).max() if len(a[0]) else 0
+    if cap and cap < rowlen:
+        cap = int(rowlen)
+
+    def same(got, lo=0, hi=M):
+        o0, o1 = want["rowptr"][lo], want["rowptr"][hi]
+        assert np.array_equal(got.rowptr, want["rowptr"][lo:hi + 1] - o0)
+        assert np.array_equal(got.colidx, want["colidx"][o0:o1])
+        assert np.array_equal(got.vals, want["vals"][o0:o1])
+
+    res = ctx.spgemm_csc_csr(M, K, N, *acsc, *bcsr, partial_capacity=cap)
+    assert res.info["partials"] == P
+    same(res)
+    SEEN["cases"] += 1
+    SEEN["long_rows"] += res.info["heavy_rows"] > 0
+    SEEN["piles"] += res.info["sorted_segments"] > 0
+    SEEN["panels"] += res.info["panels"] > 1
+    # the same product as row shards
+    G = int(rng.integers(2, 5))
+    end = 0
+    for i in range(G):
+        r = ctx.spgemm_csc_csr(M, K, N, *acsc, *bcsr, partial_capacity=cap, row_shard=(i, G))
+        assert r.info["row_begin"] == end
+        end = r.info["row_end"]
+        same(r, r.info["row_begin"], end)
+    assert end == M
+    # and a k range: the oracle restricted to the same columns of A / rows of B
+    if K > 2:
+        k0 = int(rng.integers(0, K - 1)); k1 = int(rng.integers(k0 + 1, K + 1))
+        wk = port.spgemm(M, K, N, *acsc, *bcsr, k0, k1)
+        rk = ctx.spgemm_csc_csr(M, K, N, *acsc, *bcsr, k_range=(k0, k1))
+        assert np.array_equal(rk.rowptr, wk["rowptr"]) and np.array_equal(rk.colidx, wk["colidx"])
+        assert np.array_equal(rk.vals, wk["vals"])
+
+
+def test_the_random_cases_reached_the_hard_paths():
+    """(runs after the cases above) long rows and multi-panel products must both have occurred often; piles (segments
+    beyond the big in-place tile) are covered by test_long_rows_split_and_fallback"""
+    if SEEN["cases"] < 24:
+        pytest.skip("not the whole list ran")
+    assert SEEN["long_rows"] >= 8 and SEEN["panels"] >= 8, SEEN
