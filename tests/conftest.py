@@ -10,6 +10,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+def _install_abort_trace():
+    """SIGABRT -> native backtrace on stderr (tests/abort_trace.c), then the previous handler.  Best effort."""
+    import ctypes
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = os.path.join(here, "_abort_trace.so")
+    src = os.path.join(here, "abort_trace.c")
+    try:
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.run(["gcc", "-O1", "-g", "-shared", "-fPIC", "-o", so, src], check=True, capture_output=True)
+        ctypes.CDLL(so).abort_trace_install()
+    except Exception:  # no compiler, read-only tree ...: the tests do not depend on it
+        pass
+
+
+_install_abort_trace()
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
