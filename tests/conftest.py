@@ -11,8 +11,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def _install_abort_trace():
-    """SIGABRT -> native backtrace on stderr (tests/abort_trace.c), then the previous handler.  Best effort."""
+def _install_abort_trace(fd):
+    """SIGABRT -> native backtrace on the real stderr (tests/abort_trace.c), then the previous handler.  Best effort."""
     import ctypes
     import subprocess
     here = os.path.dirname(os.path.abspath(__file__))
@@ -21,18 +21,25 @@ def _install_abort_trace():
     try:
         if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
             subprocess.run(["gcc", "-O1", "-g", "-shared", "-fPIC", "-o", so, src], check=True, capture_output=True)
-        ctypes.CDLL(so).abort_trace_install()
+        ctypes.CDLL(so).abort_trace_install(int(fd))
     except Exception:  # no compiler, read-only tree ...: the tests do not depend on it
         pass
 
 
-_install_abort_trace()
-
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+@pytest.hookimpl(trylast=True)
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # pytest points fd 2 at a capture file while a test runs; its faulthandler plugin keeps a copy of the real stderr
+    fd = None
+    try:
+        from _pytest.faulthandler import fault_handler_stderr_fd_key
+        fd = config.stash[fault_handler_stderr_fd_key]
+    except Exception:
+        pass
+    _install_abort_trace(fd if fd is not None else os.dup(2))
     # the in-tree library is a build product (git-ignored): build it once if a fresh checkout lacks it
     lib = os.path.join(ROOT, "outerspace_amd", "libouterspace_spgemm.so")
     cli = os.path.join(ROOT, "outerspace_amd", "osp_spgemm")
