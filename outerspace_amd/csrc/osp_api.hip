@@ -198,16 +198,6 @@ struct PhaseTimer {
 };
 enum { PH_SYM = 0, PH_MUL = 1, PH_MERGE = 2, PH_COMPACT = 3, PH_MUL_K = 4, PH_MERGE_K = 5 };
 
-// debugging aids: OSP_SPLIT_ROW_MAX moves the boundary between the two split kernels (tests run both on small inputs),
-// OSP_GEN_ROWS=0 stages every row (the pure outer-product formulation)
-static inline uint64_t split_row_max() {
-    const char *e = getenv("OSP_SPLIT_ROW_MAX");
-    return e ? strtoull(e, nullptr, 10) : kSplitRowMax;
-}
-static inline bool gen_rows_enabled() {
-    const char *e = getenv("OSP_GEN_ROWS");
-    return !(e && e[0] == '0');
-}
 static inline unsigned grid_for(uint64_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 static inline int bits_for(uint64_t n) {  // bits needed to represent values in [0, n)
     int b = 0;
@@ -236,7 +226,6 @@ template <class T> struct MergeIO {
     const uint64_t *row_off; uint64_t r0, r1, base;
     int64_t *c_rowptr; uint32_t *c_col; T *c_val;  // output (c_rowptr indexed by absolute row id)
     const uint64_t *out_in; uint64_t *out_out;    // entries written before / after this call (device)
-    ChunkTable<T> ct;                               // generated rows (ct.rule.enabled); ct.rule.row_max is always set
 };
 
 struct TilePlan {
@@ -311,7 +300,8 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         uint64_t *nhist = sc.get<uint64_t>(nlong);
         uint64_t *blkbase = sc.get<uint64_t>((uint64_t)nlong + 1), *hbase = sc.get<uint64_t>((uint64_t)nlong + 1);
         vbase = sc.get<uint64_t>((uint64_t)nlong + 1);
-        const uint64_t row_max = io.ct.rule.row_max;
+        // debugging aid: OSP_SPLIT_ROW_MAX moves the boundary between the two split kernels (tests run both on small inputs)
+        const uint64_t row_max = getenv("OSP_SPLIT_ROW_MAX") ? strtoull(getenv("OSP_SPLIT_ROW_MAX"), nullptr, 10) : kSplitRowMax;
         split_params_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(p0.long_rows, nlong, io.row_off, colbits, row_max, hbits, nstretch, nseg, nhist);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nstretch}, nlong, blkbase, hscan_tmp, s);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nseg}, nlong, vbase, hscan_tmp, s);
@@ -329,10 +319,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         uint8_t *vfirst = sc.get<uint8_t>(nvirt + 1);
         // rows up to kSplitRowMax: one workgroup each (histogram, scan and scatter in one kernel)
         split_row_kernel<T><<<nlong, kSplitThreads, 0, s>>>(p0.long_rows, nlong, hbits, nstretch, vbase, hoff, io.row_off, base, colbits,
-                                                            io.stage, qstage, vrow_off, io.ct.rowfirst, io.ct.rule);
-        if (io.ct.rule.enabled)  // generated rows: never staged, computed row-wise by the split itself
-            split_row_gen_kernel<T><<<nlong, kSplitThreads, 0, s>>>(p0.long_rows, nlong, hbits, nstretch, vbase, hoff, io.row_off, colbits,
-                                                                    io.ct, qstage, vrow_off);
+                                                            io.stage, qstage, vrow_off);
         if (nblocks) {  // longer rows: one workgroup per 4096-entry stretch, offsets from a device-wide scan
             split_count_kernel<<<(unsigned)nblocks, kSplitThreads, 0, s>>>(p0.long_rows, nlong, blkbase, hbase, hbits, nstretch, io.row_off,
                                                                          base, colbits, (const char *)io.stage, (uint32_t)sizeof(Part<T>), ghist);
@@ -445,13 +432,10 @@ template <class T>
 static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_t M_all, uint64_t N,
                            const uint64_t *d_row_off,
                            uint64_t P, uint64_t cap_cfg, PhaseTimer &tm, uint64_t r_lo = 0, uint64_t r_hi = ~0ull,
-                           uint64_t off_lo = 0, const PanelSink *sink = nullptr, const ChunkTable<T> *ct_in = nullptr) {
+                           uint64_t off_lo = 0, const PanelSink *sink = nullptr) {
     // output rows [r_lo, r_hi) only (row-sharded multi-GPU mode); P = their partial products, off_lo = row_off[r_lo]
     if (r_hi == ~0ull) r_hi = M_all;
     const uint64_t M = r_hi - r_lo;
-    ChunkTable<T> ct{};
-    if (ct_in) ct = *ct_in;
-    else ct.rule = GenRule{(uint64_t)TileCap<T>::value, split_row_max(), 0, false};
     res->info.M = M;
     res->info.row_begin = r_lo;
     res->info.row_end = r_hi;
@@ -563,7 +547,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
             tm.end(PH_MUL);
             tm.begin(PH_MERGE);
             OSP_HIP(hipMemsetAsync(cells, 0, 2 * sizeof(uint64_t), s));
-            MergeIO<T> io{stage, d_row_off, r0, r1, base, prow - r0, c_col, c_val, cells, cells + 1, ct};
+            MergeIO<T> io{stage, d_row_off, r0, r1, base, prow - r0, c_col, c_val, cells, cells + 1};
             merge_panel<T>(ctx, res, tm, io, colbits);
             tm.end(PH_MERGE);
             const uint64_t nnz_p = d2h(cells + 1, s);  // synchronises: the panel is complete
@@ -586,7 +570,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         tm.end(PH_MUL);
         // ---- merge ----
         tm.begin(PH_MERGE);
-        MergeIO<T> io{stage, d_row_off, r0, r1, base, res->rowptr - r_lo, c_col, c_val, out_nnz + p, out_nnz + p + 1, ct};
+        MergeIO<T> io{stage, d_row_off, r0, r1, base, res->rowptr - r_lo, c_col, c_val, out_nnz + p, out_nnz + p + 1};
         merge_panel<T>(ctx, res, tm, io, colbits);
         tm.end(PH_MERGE);
     }
@@ -772,33 +756,27 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
 
     // ---- symbolic: chunk offsets in (row, k) order ----
     tm.begin(PH_SYM);
-    const int colbits_c = std::max(1, bits_for(N));
-    const GenRule rule{(uint64_t)TileCap<T>::value, split_row_max(), colbits_c, gen_rows_enabled()};
     uint64_t *row_off = sc.get<uint64_t>(M + 1);
-    uint32_t *rowfirst = sc.get<uint32_t>(M + 1);
     uint64_t *chunk_off = sc.get<uint64_t>(nnz);
-    // A's non-zeros in (row, k) order: kept for the whole product (generated rows are computed from it)
-    uint64_t *offs_sorted = sc.get<uint64_t>(nnz + 1);
-    uint32_t *perm = sc.get<uint32_t>(nnz), *bs_sorted = sc.get<uint32_t>(nnz);
     uint64_t P = 0;
     if (nnz == 0) {
         OSP_HIP(hipMemsetAsync(row_off, 0, (M + 1) * sizeof(uint64_t), s));
-        OSP_HIP(hipMemsetAsync(rowfirst, 0, (M + 1) * sizeof(uint32_t), s));
     } else {
         Scratch ss(ctx);
         uint32_t *ka = ss.get<uint32_t>(nnz), *pa = ss.get<uint32_t>(nnz), *kb = ss.get<uint32_t>(nnz), *pb = ss.get<uint32_t>(nnz);
-        uint32_t *rows_sorted = ss.get<uint32_t>(nnz), *w_sorted = ss.get<uint32_t>(nnz);
+        uint32_t *rows_sorted = ss.get<uint32_t>(nnz), *perm = ss.get<uint32_t>(nnz), *w_sorted = ss.get<uint32_t>(nnz);
         uint32_t *hist = ss.get<uint32_t>(rs_hist_entries(nnz));
         uint32_t *hist_tmp = ss.get<uint32_t>(scan_scratch_entries(rs_hist_entries(nnz)));
+        uint64_t *offs_sorted = ss.get<uint64_t>(nnz + 1);
         uint64_t *scan_tmp = ss.get<uint64_t>(scan_scratch_entries(nnz));
-        // (row, k) order of A's non-zeros; the last sort pass also looks up each chunk's length and B row
-        uint32_t *w = ss.get<uint32_t>(nnz), *bs = ss.get<uint32_t>(nnz);
-        sym_chunk_len_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(a_colptr, b_rowptr, k0, k1, e0, nnz, w, bs);
+        // (row, k) order of A's non-zeros; the last sort pass also looks up each chunk's length
+        uint32_t *w = ss.get<uint32_t>(nnz);
+        sym_chunk_len_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(a_colptr, b_rowptr, k0, k1, e0, nnz, w);
         device_sort_rows<SymEpilogue>(a_rowidx + e0, nnz, std::max(1, bits_for(M)), ka, pa, kb, pb, hist, hist_tmp,
-                                      SymEpilogue{w, bs, rows_sorted, perm, w_sorted, bs_sorted}, s);
+                                      SymEpilogue{w, rows_sorted, perm, w_sorted}, s);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{w_sorted}, nnz, offs_sorted, scan_tmp, s);
-        sym_row_offsets_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(rows_sorted, offs_sorted, nnz, M, row_off, rowfirst);
-        sym_scatter_offsets_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(perm, offs_sorted, rows_sorted, row_off, rowfirst, rule, nnz, chunk_off);
+        sym_scatter_offsets_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(perm, offs_sorted, nnz, chunk_off);
+        sym_row_offsets_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(rows_sorted, offs_sorted, nnz, M, row_off);
         P = d2h(offs_sorted + nnz, s);
     }
     tm.end(PH_SYM);
@@ -816,8 +794,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
 
     // row-sharded: A holds this rank's rows only, so the staging offsets start at 0 at r_lo and P is the shard's count
     const uint64_t off_lo = 0, P_rows = P;
-    const ChunkTable<T> ct{offs_sorted, bs_sorted, perm, rowfirst, a_vals + e0, b_colidx, b_vals, rule};
-    merge_pipeline<T>(ctx, res, prod, M, N, row_off, P_rows, cfg.partial_capacity, tm, r_lo, r_hi, off_lo, sink, &ct);
+    merge_pipeline<T>(ctx, res, prod, M, N, row_off, P_rows, cfg.partial_capacity, tm, r_lo, r_hi, off_lo, sink);
 
     OSP_HIP(hipEventRecord(ev1, s));
     OSP_HIP(hipStreamSynchronize(s));

@@ -28,36 +28,6 @@ template <> struct TileCap<double> { static constexpr int value = 1536; };
 constexpr int kMergeThreads = 256;
 constexpr int kTileMaxRows = kMergeThreads - 1;  // rows per tile: 8 row bits in the sort key, one row offset per thread
 constexpr int kMulThreads = 256;
-
-// ---- how a long row (more partial products than a tile) is handled ----
-constexpr int kSplitMaxBits = 12;     // at most 4096 column ranges ("segments") per row
-constexpr int kSplitTarget = 256;     // aim for segments of about this many entries
-constexpr int kSplitRowBits = 8;      // rows of at most 2^8 segments (<= 64K entries) are split by ONE workgroup
-constexpr uint64_t kSplitRowMax = (uint64_t)kSplitTarget << kSplitRowBits;  // longer rows: one workgroup per stretch
-constexpr uint32_t kGenMaxChunks = 2048;  // a generated row's chunk table must fit the split workgroup's LDS
-__host__ __device__ inline int split_bits(uint64_t U, int colbits) {
-    const uint64_t want = (U + kSplitTarget - 1) / kSplitTarget;
-    int b = 1;
-    while (b < kSplitMaxBits && (1ull << b) < want) b++;
-    return b < colbits ? b : colbits;
-}
-// split by one workgroup (else: one workgroup per 4096-entry stretch)
-__host__ __device__ inline bool row_one_workgroup(uint64_t U, int colbits, uint64_t row_max) {
-    return U <= row_max && split_bits(U, colbits) <= kSplitRowBits;
-}
-// GENERATED rows: a long row that one workgroup splits is never staged -- the split kernel computes its partial
-// products itself, row-wise, from A's row and the B rows it touches (osp_split.h: split_row_gen_kernel), and the
-// multiply phase skips it.  One predicate, used by the symbolic phase (which marks the chunks to skip) and by both
-// split kernels, so that they always agree.
-__host__ __device__ inline bool row_generated(uint64_t U, uint64_t nchunks, uint64_t cap, int colbits, uint64_t row_max, bool enabled) {
-    return enabled && U > cap && nchunks <= kGenMaxChunks && row_one_workgroup(U, colbits, row_max);
-}
-constexpr uint64_t kChunkSkip = ~0ull;  // chunk_off of a chunk the multiply phase must not write
-struct GenRule {
-    uint64_t cap, row_max;
-    int colbits;
-    bool enabled;
-};
 constexpr int kMulPerWave = 2048;  // partial products per wave slice
 constexpr int kMulPerBlock = kMulPerWave * (kMulThreads / kWave);
 
@@ -158,39 +128,21 @@ struct LoadGatherW {  // w in row order
     __device__ uint64_t operator()(uint64_t t) const { return w[perm[t]]; }
 };
 
-// chunk_off[perm[t]] = offs_sorted[t], or kChunkSkip for the chunks of generated rows (see row_generated)
-// A's non-zeros in (row, k) order with what a generated row needs to compute its partial products itself
-template <class T>
-struct ChunkTable {
-    const uint64_t *off;       // staging offset of chunk t (nnz + 1 entries): row i's products are [off[first], off[first'])
-    const uint32_t *bs;        // first entry of the chunk's B row in b_colidx / b_vals
-    const uint32_t *perm;      // the chunk's A entry: position in a_vals (already offset to the k shard)
-    const uint32_t *rowfirst;  // first chunk of every row (M + 1 entries)
-    const T *a_vals;
-    const uint32_t *b_colidx;
-    const T *b_vals;
-    GenRule rule;
-};
-__global__ void sym_scatter_offsets_kernel(const uint32_t *perm, const uint64_t *offs_sorted, const uint32_t *rows_sorted,
-                                           const uint64_t *row_off, const uint32_t *rowfirst, GenRule rule, uint64_t nnz,
-                                           uint64_t *chunk_off) {
+// chunk_off[perm[t]] = offs_sorted[t]
+__global__ void sym_scatter_offsets_kernel(const uint32_t *perm, const uint64_t *offs_sorted,
+                                           uint64_t nnz, uint64_t *chunk_off) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nnz) return;
-    const uint32_t r = rows_sorted[t];
-    const bool gen = row_generated(row_off[r + 1] - row_off[r], rowfirst[r + 1] - rowfirst[r], rule.cap, rule.colbits, rule.row_max,
-                                   rule.enabled);
-    chunk_off[perm[t]] = gen ? kChunkSkip : offs_sorted[t];
+    if (t < nnz) chunk_off[perm[t]] = offs_sorted[t];
 }
 
 // row_off[i] = staging offset of row i's first partial product, arow[i] = index of its first
 // non-empty chunk, i in [0, M]
 __global__ void sym_row_offsets_kernel(const uint32_t *rows_sorted, const uint64_t *offs_sorted, uint64_t nnz, uint64_t M,
-                                       uint64_t *row_off, uint32_t *rowfirst) {
+                                       uint64_t *row_off) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > M) return;
     uint64_t t = lower_bound_dev(rows_sorted, 0, nnz, (uint64_t)i);
     row_off[i] = offs_sorted[t];  // offs_sorted has nnz+1 entries, [nnz] = P
-    rowfirst[i] = (uint32_t)t;    // row i's chunks are entries [rowfirst[i], rowfirst[i+1]) of the (row, k) order
 }
 struct LenGatherW {  // chunk length of the t-th A entry in (row, k) order
     const uint32_t *w;
@@ -279,12 +231,8 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
             for (uint64_t jb = j0; jb <= j1; jb += kWave) {
                 const uint64_t jm = jb + lane;
                 T av_l = 0;
-                uint64_t off_l = kChunkSkip;
-                if (jm <= j1) {
-                    av_l = a_vals[as + jm];
-                    const uint64_t raw = chunk_off[as + jm - (uint64_t)e0];
-                    off_l = raw == kChunkSkip ? kChunkSkip : raw - base;
-                }
+                uint64_t off_l = 0;
+                if (jm <= j1) { av_l = a_vals[as + jm]; off_l = chunk_off[as + jm - (uint64_t)e0] - base; }
                 const uint32_t cj = (uint32_t)min((uint64_t)kWave, j1 - jb + 1);
                 for (uint32_t l0 = 0; l0 < nb; l0 += kWave) {
                     const uint32_t l = l0 + lane;
@@ -295,7 +243,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                         const uint64_t j = jb + q;
                         const T av = wave_bcast(av_l, q);
                         const uint64_t off = wave_bcast(off_l, q);
-                        const bool ok = in && off != kChunkSkip && !(j == j0 && l < la) && !(j == j1 && l >= lb);
+                        const bool ok = in && !(j == j0 && l < la) && !(j == j1 && l >= lb);
                         if (ok) stage[off + l] = Part<T>{bc, av * bv};
                     }
                 }
@@ -313,8 +261,8 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                 bool ok = in && j <= j1 && !(j == j0 && l < la) && !(j == j1 && l >= lb);
                 if (ok) {
                     const uint64_t e = as + j;
-                    const uint64_t raw = chunk_off[e - (uint64_t)e0];
-                    if (raw != kChunkSkip) stage[raw - base + l] = Part<T>{bc, a_vals[e] * bv};
+                    const uint64_t off = chunk_off[e - (uint64_t)e0] - base;
+                    stage[off + l] = Part<T>{bc, a_vals[e] * bv};
                 }
             }
         }

@@ -17,7 +17,10 @@ namespace osp {
 
 constexpr int kSplitThreads = 256;
 constexpr int kSplitStretch = 4096;   // entries of one long row handled by one workgroup
-// (kSplitMaxBits, kSplitTarget, kSplitRowBits, kSplitRowMax and the row classification live in osp_kernels.h)
+constexpr int kSplitMaxBits = 12;     // at most 4096 segments per row
+constexpr int kSplitTarget = 256;     // aim for segments of about this many entries
+constexpr int kSplitRowBits = 8;      // rows of at most 2^8 segments (<= 64K entries) are split by ONE workgroup
+constexpr uint64_t kSplitRowMax = (uint64_t)kSplitTarget << kSplitRowBits;  // longer rows: one workgroup per stretch
 
 // per long row h: b = number of split bits, and the sizes that get scanned
 __global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *row_off, int colbits,
@@ -25,8 +28,11 @@ __global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= nheavy) return;
     const uint64_t U = row_off[rows[h] + 1] - row_off[rows[h]];
-    const int b = split_bits(U, colbits);
-    const bool big = !row_one_workgroup(U, colbits, row_max);
+    const uint64_t want = (U + kSplitTarget - 1) / kSplitTarget;
+    int b = 1;
+    while (b < kSplitMaxBits && (1ull << b) < want) b++;
+    b = min(b, colbits);
+    const bool big = U > row_max || b > kSplitRowBits;
     const uint32_t ns = big ? (uint32_t)((U + kSplitStretch - 1) / kSplitStretch) : 0u;  // 0 stretches = one-workgroup row
     hbits[h] = (uint8_t)b;
     nstretch[h] = ns;
@@ -173,7 +179,7 @@ template <class T>
 __global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
     const uint32_t *rows, uint32_t nheavy, const uint8_t *hbits, const uint32_t *nstretch, const uint64_t *vbase,
     const uint64_t *hoff, const uint64_t *row_off, uint64_t base, int colbits, const Part<T> *stage, Part<T> *qstage,
-    uint64_t *vrow_off, const uint32_t *rowfirst, GenRule rule) {
+    uint64_t *vrow_off) {
     constexpr int NW = kSplitThreads / kWave;
     constexpr int ITERS = kSplitStretch / kSplitThreads;
     constexpr int NSEG = 1 << kSplitRowBits;
@@ -187,8 +193,6 @@ __global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
     const uint32_t b = hbits[h], nseg = 1u << b;
     const int sh = colbits - (int)b;
     const uint64_t beg = row_off[rows[h]] - base, end = row_off[rows[h] + 1] - base;
-    if (rule.enabled && row_generated(end - beg, rowfirst[rows[h] + 1] - rowfirst[rows[h]], rule.cap, rule.colbits, rule.row_max, true))
-        return;  // never staged: split_row_gen_kernel computes it
     const uint64_t qbase = hoff[h];
     for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) segoff[d] = 0;
     __syncthreads();
@@ -252,139 +256,4 @@ __global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
         // (the zeroing of cnt at the top of the next round touches the same d from the same thread)
     }
 }
-// GENERATED rows (see row_generated, osp_kernels.h): the same split, but the row's partial products are computed here,
-// row-wise, instead of being read from the staging buffer -- A's row is the chunk table (one entry per non-zero A[i,k]:
-// where its products start in the row, where B's row k starts, the value), product p of the row is found by a binary
-// search over it and gathered from B.  The multiply phase never writes these rows: 12 bytes less written and 24 less
-// read per partial product; order and arithmetic (a * b, staging order = k ascending) are the staged path's.
-template <class T>
-__global__ __launch_bounds__(kSplitThreads) void split_row_gen_kernel(
-    const uint32_t *rows, uint32_t nheavy, const uint8_t *hbits, const uint32_t *nstretch, const uint64_t *vbase,
-    const uint64_t *hoff, const uint64_t *row_off, int colbits, ChunkTable<T> ct, Part<T> *qstage, uint64_t *vrow_off) {
-    constexpr int NW = kSplitThreads / kWave;
-    constexpr int ITERS = kSplitStretch / kSplitThreads;
-    constexpr int NSEG = 1 << kSplitRowBits;
-    constexpr int SPT = NSEG / kSplitThreads;
-    static_assert(NSEG % kSplitThreads == 0, "whole segments per thread in the scan");
-    __shared__ uint32_t coff[kGenMaxChunks + 1];  // first product of every chunk, relative to the row
-    __shared__ uint32_t cbs[kGenMaxChunks];       // first entry of its B row
-    __shared__ T cav[kGenMaxChunks];              // A[i,k]
-    __shared__ uint16_t cnt[NW + 1][NSEG];
-    __shared__ uint32_t segoff[NSEG];
-    __shared__ uint32_t scratch[NW + 1];
-    const uint32_t h = blockIdx.x;
-    if (h >= nheavy || nstretch[h] != 0) return;
-    const uint32_t row = rows[h];
-    const uint32_t c0 = ct.rowfirst[row], nc = ct.rowfirst[row + 1] - c0;
-    const uint64_t rbeg = row_off[row];
-    const uint32_t U = (uint32_t)(row_off[row + 1] - rbeg);
-    if (!row_generated(U, nc, ct.rule.cap, ct.rule.colbits, ct.rule.row_max, ct.rule.enabled)) return;
-    const unsigned lane = lane_id(), w = threadIdx.x >> 6;
-    const uint32_t b = hbits[h], nseg = 1u << b;
-    const int sh = colbits - (int)b;
-    const uint64_t qbase = hoff[h];
-    for (uint32_t c = threadIdx.x; c < nc; c += kSplitThreads) {
-        coff[c] = (uint32_t)(ct.off[c0 + c] - rbeg);
-        cbs[c] = ct.bs[c0 + c];
-        cav[c] = ct.a_vals[ct.perm[c0 + c]];
-    }
-    if (threadIdx.x == 0) coff[nc] = U;
-    for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) segoff[d] = 0;
-    __syncthreads();
-    // product p of the row -> (chunk, entry of B): the LAST chunk whose first product is <= p (empty chunks -- B rows
-    // without entries -- share their successor's offset and are passed over).  Products are visited in order, so a
-    // wave keeps a cursor: one binary search where its span starts, then short forward walks.
-    auto first_chunk = [&](uint32_t p) -> uint32_t {
-        uint32_t lo = 0, hi = nc;
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (coff[mid] <= p) lo = mid; else hi = mid; }
-        return lo;
-    };
-    auto walk = [&](uint32_t c, uint32_t p) -> uint32_t {  // from a chunk at or before p's
-        while (c + 1 < nc && coff[c + 1] <= p) c++;
-        return c;
-    };
-    {   // histogram of the row's products over its segments: each wave takes a contiguous quarter of the row
-        const uint32_t per = ((U + NW - 1) / NW + kWave - 1) / kWave * kWave;
-        const uint32_t pb = min(w * per, U), pe = min(pb + per, U);
-        uint32_t cur = pb < pe ? first_chunk(pb) : 0u;
-        for (uint32_t p0 = pb; p0 < pe; p0 += kWave) {
-            cur = walk(cur, p0);  // wave-uniform
-            const uint32_t p = p0 + lane;
-            if (p < pe) {
-                const uint32_t c = walk(cur, p);
-                atomicAdd(&segoff[ct.b_colidx[cbs[c] + (p - coff[c])] >> sh], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    {   // exclusive scan of the segment counts -> segment offsets
-        uint32_t cc[SPT], sum = 0;
-#pragma unroll
-        for (int q = 0; q < SPT; q++) { const uint32_t d = threadIdx.x * SPT + q; cc[q] = d < nseg ? segoff[d] : 0u; sum += cc[q]; }
-        uint32_t total;
-        uint32_t ex = block_excl_scan<uint32_t, kSplitThreads>(sum, scratch, &total);
-#pragma unroll
-        for (int q = 0; q < SPT; q++) {
-            const uint32_t d = threadIdx.x * SPT + q;
-            if (d < nseg) { segoff[d] = ex; vrow_off[vbase[h] + d] = qbase + ex; }
-            ex += cc[q];
-        }
-    }
-    __syncthreads();
-    for (uint32_t sb = 0; sb < U; sb += kSplitStretch) {
-        const uint32_t se = min(sb + (uint32_t)kSplitStretch, U);
-        for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) {
-#pragma unroll
-            for (int ww = 0; ww < NW; ww++) cnt[ww][d] = 0;
-        }
-        __syncthreads();  // also orders the segoff update of the previous round before this round's scatter
-        const uint32_t wbeg = sb + w * (kSplitStretch / NW);
-        uint32_t rk[ITERS], kc[ITERS];
-        T kv[ITERS];
-        uint32_t cur = wbeg < se ? first_chunk(wbeg) : 0u;
-#pragma unroll
-        for (int it = 0; it < ITERS; it++) {
-            const uint32_t i0 = wbeg + it * kWave;
-            if (i0 < se) cur = walk(cur, i0);  // wave-uniform
-            const uint32_t i = i0 + lane;
-            const uint32_t c = walk(cur, i < se ? i : (i0 < se ? i0 : sb));  // lanes past the end recompute a valid product
-            const uint32_t src = cbs[c] + ((i < se ? i : (i0 < se ? i0 : sb)) - coff[c]);
-            kc[it] = ct.b_colidx[src];
-            kv[it] = cav[c] * ct.b_vals[src];
-        }
-#pragma unroll
-        for (int it = 0; it < ITERS; it++) {
-            const uint32_t i = wbeg + it * kWave + lane;
-            const bool valid = i < se;
-            const unsigned d = kc[it] >> sh;
-            unsigned r, c;
-            wave_match_bits(d, (int)b, valid, r, c);
-            rk[it] = 0;
-            if (valid) {
-                const uint32_t cur = cnt[w][d];
-                rk[it] = cur + r;
-                if (r == 0) cnt[w][d] = (uint16_t)(cur + c);
-            }
-        }
-        __syncthreads();
-        for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) {
-            uint32_t run = 0;
-#pragma unroll
-            for (int ww = 0; ww < NW; ww++) { const uint32_t c = cnt[ww][d]; cnt[ww][d] = (uint16_t)run; run += c; }
-            cnt[NW][d] = (uint16_t)run;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < ITERS; it++) {
-            const uint32_t i = wbeg + it * kWave + lane;
-            if (i < se) {
-                const unsigned d = kc[it] >> sh;
-                qstage[qbase + segoff[d] + cnt[w][d] + rk[it]] = Part<T>{kc[it], kv[it]};
-            }
-        }
-        __syncthreads();
-        for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) segoff[d] += cnt[NW][d];
-    }
-}
-
 }  // namespace osp
