@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <string>
@@ -52,6 +53,10 @@ struct Context {
     std::map<void *, size_t> live;
     size_t pooled_bytes = 0;
     uint32_t cus = 256;  // persistent kernels size their grids from this
+    // pool misses (OSP_VERBOSE prints them per product): device allocations are slow, a product should not need any
+    // once the pool is warm
+    uint64_t malloc_calls = 0, malloc_bytes = 0;
+    double malloc_ms = 0;
 
     static size_t bucket(size_t bytes) {
         if (bytes < 4096) return 4096;
@@ -112,9 +117,25 @@ struct Context {
             free_list.erase(it);
             pooled_bytes -= b;
         } else {
+            const auto t0 = std::chrono::steady_clock::now();
             hipError_t e = hipMalloc(&p, b);
+            if (e != hipSuccess) {
+                // out of memory.  First choice: a pooled block that is merely too generous for the 1.5x rule (the
+                // multi-GB scratch of a panel drifts from panel to panel; freeing such blocks only to allocate them
+                // again cost a third of the run time of the streamed Graph500 products).
+                (void)hipGetLastError();
+                it = free_list.lower_bound(b);
+                if (it != free_list.end()) {
+                    p = it->second;
+                    b = it->first;
+                    free_list.erase(it);
+                    pooled_bytes -= b;
+                    live[p] = b;
+                    return p;
+                }
+            }
             while (e != hipSuccess && !free_list.empty()) {
-                // out of memory: give the largest pooled blocks back until the request fits
+                // still nothing: give the largest pooled blocks back until the request fits
                 (void)hipGetLastError();
                 auto big = std::prev(free_list.end());
                 (void)hipFree(big->second);
@@ -126,6 +147,13 @@ struct Context {
                 (void)hipGetLastError();
                 throw Error(OSP_ERR_ALLOC, "hipMalloc of " + std::to_string(b) + " bytes failed");
             }
+            malloc_calls++;
+            malloc_bytes += b;
+            const double dt = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            malloc_ms += dt;
+            if (b >= (1ull << 30) && getenv("OSP_VERBOSE"))
+                fprintf(stderr, "[osp]   pool miss: hipMalloc of %.2f GB took %.0f ms (pooled %.1f GB in %zu blocks, live %zu blocks)\n", b / 1e9, dt,
+                        pooled_bytes / 1e9, free_list.size(), live.size());
         }
         live[p] = b;
         // debugging aid: OSP_POISON=1 fills every buffer with 0xFF bytes, so that a read of memory nobody
@@ -142,6 +170,20 @@ struct Context {
         free_list.emplace(it->second, p);
         pooled_bytes += it->second;
         live.erase(it);
+    }
+    // Leave `bytes` of device memory to others (the consumer of a streamed panel runs its own kernels and allocations
+    // while this pool may hold everything): hand pooled blocks back, small ones first -- they are the cheap ones to
+    // allocate again.
+    void ensure_free(size_t bytes) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
+        while (free_b < bytes && !free_list.empty()) {
+            auto it = free_list.begin();
+            (void)hipFree(it->second);
+            pooled_bytes -= it->first;
+            free_b += it->first;
+            free_list.erase(it);
+        }
     }
     void trim() {
         for (auto &kv : free_list) (void)hipFree(kv.second);
@@ -553,6 +595,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
             const uint64_t nnz_p = d2h(cells + 1, s);  // synchronises: the panel is complete
             nnz_total += nnz_p;
             const osp_panel_t pd{r0, r1, nnz_p, prow, c_col, c_val, p, npanels, {0, 0}};
+            ctx->ensure_free(2ull << 30);  // the consumer needs room of its own
             if (sink->fn(&pd, sink->user)) throw Error(OSP_ERR_ARG, "panel callback returned non-zero");
             OSP_HIP(hipStreamSynchronize(s));  // whatever the callback queued on this stream reads the buffers
         }
@@ -800,6 +843,10 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     OSP_HIP(hipStreamSynchronize(s));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ev0, ev1);
+    if (getenv("OSP_VERBOSE")) {
+        fprintf(stderr, "[osp] product done in %.1f ms; pool misses so far: %llu hipMalloc calls, %.1f GB, %.1f ms\n", ms,
+                (unsigned long long)ctx->malloc_calls, ctx->malloc_bytes / 1e9, ctx->malloc_ms);
+    }
     res->info.ms_total = ms;
     res->info.ms_symbolic = tm.total(PH_SYM);
     res->info.ms_multiply = tm.total(PH_MUL);
