@@ -60,3 +60,14 @@ def port():
     from oracle import oracle
     oracle.build(ref=os.path.exists("/root/reference/simulator/SimSpGEMM.cpp"))
     return oracle.port()
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """ONE library context (device 0: stream + buffer pool) for the whole session.  A context per test module meant
+    freeing every pooled device buffer and allocating the same addresses again a moment later; the intermittent GPU
+    memory faults of round 1 clustered right after such a hand-over, and a process normally keeps one context anyway."""
+    from outerspace_amd import spgemm as S
+    c = S.Context(0)
+    yield c
+    c.close()

@@ -10,14 +10,6 @@ pytestmark = pytest.mark.gpu
 SEEN = {"cases": 0, "long_rows": 0, "piles": 0, "panels": 0}
 
 
-@pytest.fixture(scope="module")
-def ctx():
-    from outerspace_amd import spgemm as S
-    c = S.Context(0)
-    yield c
-    c.close()
-
-
 def skewed_coo(rng, nrow, ncol, nnz, alpha, dtype):
     """nnz distinct coordinates; row and column ids drawn from a power law (alpha = 0: uniform) so that a few rows /
     columns are hubs -- long rows, over-long segments and piles all appear at small sizes."""

@@ -17,14 +17,6 @@ pytestmark = pytest.mark.gpu
 RTOL = {np.dtype(np.float32): 1e-5, np.dtype(np.float64): 1e-6}
 
 
-@pytest.fixture(scope="module")
-def ctx():
-    from outerspace_amd import spgemm as S
-    c = S.Context(0)
-    yield c
-    c.close()
-
-
 def load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name))
 
