@@ -247,10 +247,53 @@ static inline int bits_for(uint64_t n) {  // bits needed to represent values in 
     return b;
 }
 
+// Host <-> device copies go through a pinned staging buffer owned by this library, never straight from or to the
+// caller's pageable memory: hipMemcpyAsync on pageable memory pins and unpins the caller's pages on the fly, and
+// round 1 saw intermittent "Memory access fault by GPU" aborts on HOST addresses in exactly the runs that passed host
+// operands (pytest, the gloo rehearsal) and never in the ones that passed device pointers (bench.py).
+struct Pinned {
+    char *p = nullptr;
+    size_t bytes = 0;
+    char *get(size_t want) {
+        if (bytes < want) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr;
+            bytes = 0;
+            if (hipHostMalloc((void **)&p, want, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                throw Error(OSP_ERR_ALLOC, "hipHostMalloc of the staging buffer failed");
+            }
+            bytes = want;
+        }
+        return p;
+    }
+};
+static Pinned &pinned_buffer() {
+    static thread_local Pinned b;  // lives as long as the thread; a few MB
+    return b;
+}
+constexpr size_t kStageChunk = 16u << 20;
+static void copy_h2d(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    char *pin = pinned_buffer().get(std::min(bytes, kStageChunk));
+    for (size_t off = 0; off < bytes; off += kStageChunk) {
+        const size_t n = std::min(kStageChunk, bytes - off);
+        memcpy(pin, (const char *)src + off, n);
+        OSP_HIP(hipMemcpyAsync((char *)dst + off, pin, n, hipMemcpyHostToDevice, s));
+        OSP_HIP(hipStreamSynchronize(s));  // the one staging buffer is reused by the next chunk
+    }
+}
+static void copy_d2h(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    char *pin = pinned_buffer().get(std::min(std::max<size_t>(bytes, 64), kStageChunk));
+    for (size_t off = 0; off < bytes; off += kStageChunk) {
+        const size_t n = std::min(kStageChunk, bytes - off);
+        OSP_HIP(hipMemcpyAsync(pin, (const char *)src + off, n, hipMemcpyDeviceToHost, s));
+        OSP_HIP(hipStreamSynchronize(s));
+        memcpy((char *)dst + off, pin, n);
+    }
+}
 template <class T> static T d2h(const T *dptr, hipStream_t s) {
     T v;
-    OSP_HIP(hipMemcpyAsync(&v, dptr, sizeof(T), hipMemcpyDeviceToHost, s));
-    OSP_HIP(hipStreamSynchronize(s));
+    copy_d2h(&v, dptr, sizeof(T), s);
     return v;
 }
 
@@ -541,8 +584,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         bounds.push_back(r_hi);
     } else {
         h_off_v.resize(M + 1);
-        OSP_HIP(hipMemcpyAsync(h_off_v.data(), d_row_off + r_lo, (M + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-        OSP_HIP(hipStreamSynchronize(s));
+        copy_d2h(h_off_v.data(), d_row_off + r_lo, (M + 1) * sizeof(uint64_t), s);
         uint64_t r = 0;
         while (r < M) {
             // largest r1 with row_off[r1] - row_off[r] <= cap
@@ -678,7 +720,7 @@ template <class T>
 static const T *to_device(Scratch &sc, const T *p, uint64_t n, osp_memspace_t space, hipStream_t s) {
     if (space == OSP_DEVICE || n == 0) return p;
     T *d = sc.get<T>(n);
-    OSP_HIP(hipMemcpyAsync(d, p, n * sizeof(T), hipMemcpyHostToDevice, s));
+    copy_h2d(d, p, n * sizeof(T), s);
     return d;
 }
 
@@ -768,8 +810,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
             device_exclusive_scan<RowCost, uint64_t>(RowCost{pre, (uint64_t)TileCap<T>::value, kSplitRowMax}, M, cost_pre, tmp, s);
             shard_bounds_kernel<<<grid_for(G + 1, 64), 64, 0, s>>>(cost_pre, pre, M, G, d_b, d_b + G + 1);
             std::vector<uint64_t> h_b(2ull * (G + 1));
-            OSP_HIP(hipMemcpyAsync(h_b.data(), d_b, h_b.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-            OSP_HIP(hipStreamSynchronize(s));
+            copy_d2h(h_b.data(), d_b, h_b.size() * sizeof(uint64_t), s);
             r_lo = h_b[cfg.row_shard_index];
             r_hi = h_b[cfg.row_shard_index + 1];
         }
@@ -951,9 +992,9 @@ static void merge_parts_impl(Context *ctx, Result *res, uint64_t M, uint64_t N, 
     const int64_t **d_rp = (const int64_t **)sc.get<void *>(nparts);
     const uint32_t **d_ci = (const uint32_t **)sc.get<void *>(nparts);
     const T **d_va = (const T **)sc.get<void *>(nparts);
-    OSP_HIP(hipMemcpyAsync(d_rp, rp.data(), nparts * sizeof(void *), hipMemcpyHostToDevice, s));
-    OSP_HIP(hipMemcpyAsync(d_ci, ci.data(), nparts * sizeof(void *), hipMemcpyHostToDevice, s));
-    OSP_HIP(hipMemcpyAsync(d_va, va.data(), nparts * sizeof(void *), hipMemcpyHostToDevice, s));
+    copy_h2d(d_rp, rp.data(), nparts * sizeof(void *), s);
+    copy_h2d(d_ci, ci.data(), nparts * sizeof(void *), s);
+    copy_h2d(d_va, va.data(), nparts * sizeof(void *), s);
     tm.begin(PH_SYM);
     const uint64_t ncand = M * (uint64_t)nparts;  // candidate chunk (r, p) = row r of part p
     uint64_t *row_off = sc.get<uint64_t>(M + 1);
@@ -1233,11 +1274,14 @@ int osp_result_copy_csr(osp_result_t r_, int64_t *rowptr, uint32_t *colidx, void
     OSP_GUARD_BEGIN
     OSP_HIP(hipSetDevice(r->ctx->device));
     hipStream_t s = r->ctx->stream;
-    const hipMemcpyKind kind = space == OSP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     const size_t vs = r->dtype == OSP_F32 ? 4 : 8;
-    if (rowptr) OSP_HIP(hipMemcpyAsync(rowptr, r->rowptr, (r->info.M + 1) * sizeof(int64_t), kind, s));
-    if (colidx && r->info.nnz_c) OSP_HIP(hipMemcpyAsync(colidx, r->colidx, r->info.nnz_c * sizeof(uint32_t), kind, s));
-    if (vals && r->info.nnz_c) OSP_HIP(hipMemcpyAsync(vals, r->vals, r->info.nnz_c * vs, kind, s));
+    auto out = [&](void *dst, const void *src, size_t bytes) {
+        if (space == OSP_HOST) copy_d2h(dst, src, bytes, s);
+        else OSP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+    };
+    if (rowptr) out(rowptr, r->rowptr, (r->info.M + 1) * sizeof(int64_t));
+    if (colidx && r->info.nnz_c) out(colidx, r->colidx, r->info.nnz_c * sizeof(uint32_t));
+    if (vals && r->info.nnz_c) out(vals, r->vals, r->info.nnz_c * vs);
     OSP_HIP(hipStreamSynchronize(s));
     return OSP_OK;
     OSP_GUARD_END
