@@ -14,8 +14,15 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"osp::([A-Za-z0-9_]+)", name)
-    return m.group(1) if m else None
+    m = re.search(r"osp::([A-Za-z0-9_]+)(<[^(]*>)?\(", name)
+    if not m:
+        return None
+    base = m.group(1)
+    if base == "merge_tiles_kernel":
+        # the tile kernel has two instantiations per value type: the chained one (mode 0, what bench.py's roofline is
+        # about) and the big in-place tiles for over-long segments (mode 32)
+        return base if re.search(r"<[^,]+, \d+, 0,", m.group(2) or "") else base + " (in-place)"
+    return base
 
 
 def load(path):
