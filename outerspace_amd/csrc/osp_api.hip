@@ -73,6 +73,33 @@ struct Context {
     struct GuardRec { char *base; size_t total, bytes; };
     std::map<void *, GuardRec> guarded;
     static bool guard_mode() { static const bool g = getenv("OSP_GUARD") != nullptr; return g; }
+    // OSP_GUARD=2 ("electric fence"): every buffer is mapped through the virtual-memory API so that it ENDS at the end
+    // of its mapping, with the address range behind it left unmapped -- an access past the end of a buffer, READS
+    // included, faults on the spot.  Nothing is ever unmapped or reused in this mode (small test inputs only): early
+    // experiments that did unmap showed stale translations, which look like bugs and are not.
+    static bool fence_mode() { static const bool g = getenv("OSP_GUARD") && atoi(getenv("OSP_GUARD")) == 2; return g; }
+    void *alloc_fenced(size_t bytes) {
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = device;
+        size_t gran = 0;
+        OSP_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
+        const size_t map_size = (bytes + gran - 1) / gran * gran;
+        char *va = nullptr;
+        hipMemGenericAllocationHandle_t h;
+        OSP_HIP(hipMemAddressReserve((void **)&va, map_size + gran, gran, nullptr, 0));
+        OSP_HIP(hipMemCreate(&h, map_size, &prop, 0));
+        OSP_HIP(hipMemMap(va, map_size, 0, h, 0));
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        OSP_HIP(hipMemSetAccess(va, map_size, &acc, 1));
+        char *user = va + (map_size - bytes) / 16 * 16;
+        OSP_HIP(hipMemsetAsync(va, 0xA5, map_size, stream));
+        if (getenv("OSP_VERBOSE")) fprintf(stderr, "[osp] fence: %zu bytes at [%p, %p), mapping ends at %p\n", bytes, (void *)user, (void *)(user + bytes), (void *)(va + map_size));
+        return user;
+    }
     void *alloc_guarded(size_t bytes) {
         const size_t total = bucket(bytes + 2 * kGuard);
         char *base = nullptr;
@@ -105,6 +132,7 @@ struct Context {
         (void)hipFree(g.base);
     }
     void *alloc(size_t bytes) {
+        if (fence_mode()) return alloc_fenced(bytes ? bytes : 1);
         if (guard_mode()) return alloc_guarded(bytes ? bytes : 1);
         size_t b = bucket(bytes ? bytes : 1);
         // best fit among pooled blocks: anything from b to 1.5 b is reused (buffer sizes drift from panel to
@@ -164,6 +192,7 @@ struct Context {
     }
     void release(void *p) {
         if (!p) return;
+        if (fence_mode()) return;  // leaked on purpose, see fence_mode()
         if (guard_mode()) { release_guarded(p); return; }
         auto it = live.find(p);
         if (it == live.end()) return;
@@ -240,6 +269,15 @@ struct PhaseTimer {
 };
 enum { PH_SYM = 0, PH_MUL = 1, PH_MERGE = 2, PH_COMPACT = 3, PH_MUL_K = 4, PH_MERGE_K = 5 };
 
+// debugging aid: OSP_SYNC=1 waits for the stream at the marked points of a product and names them on stderr, so
+// that an asynchronous GPU fault is pinned to the step that caused it (the last name printed COMPLETED)
+static inline void dbg_sync(hipStream_t s, const char *what) {
+    static const bool on = getenv("OSP_SYNC") != nullptr;
+    if (!on) return;
+    (void)hipStreamSynchronize(s);
+    fprintf(stderr, "[osp] ok: %s\n", what);
+    fflush(stderr);
+}
 static inline unsigned grid_for(uint64_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 static inline int bits_for(uint64_t n) {  // bits needed to represent values in [0, n)
     int b = 0;
@@ -490,18 +528,21 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
     uint32_t *ticket = sc.get<uint32_t>(1);
     OSP_HIP(hipMemsetAsync(tile_status, 0, (uint64_t)ntot * sizeof(uint64_t), s));
     OSP_HIP(hipMemsetAsync(ticket, 0, sizeof(uint32_t), s));
+    dbg_sync(s, "tile planning, splits, over-long segments");
     tm.begin(PH_MERGE_K);
     // persistent workgroups: as many as the LDS lets run at once
     const uint32_t merge_grid = ctx->cus * (uint32_t)merge_wgs_per_cu<T, kMergeThreads, TileCap<T>::value>();
     merge_tiles_kernel<T, kMergeThreads><<<std::min<uint32_t>(ntot, merge_grid), kMergeThreads, 0, s>>>(
         desc, ntot, lv, colbits, tile_status, ticket, io.out_in, io.c_col, io.c_val, io.out_out);
     tm.end(PH_MERGE_K);
+    dbg_sync(s, "merge tiles");
     res->info.merge_launches++;
     if (p1.nlong)
         heavy_copy_kernel<T><<<p1.nlong * 8u, 256, 0, s>>>(p1.long_rows, p1.nlong, seg_src, seg_nnz, vptr, qstage, nullptr, nullptr,
                                                            io.c_col, io.c_val);
     chain_finish_kernel<<<grid_for(std::max<uint32_t>(p0.nlong, 1), 256), 256, 0, s>>>(p0.long_rows, p0.nlong, vbase, vptr, io.out_out, r1,
                                                                                        io.c_rowptr);
+    dbg_sync(s, "copy of reduced segments, chain finish");
     OSP_HIP(hipGetLastError());  // a rejected launch must not pass silently
 }
 
@@ -695,10 +736,12 @@ template <class T> struct OuterProducer : Producer<T> {
                                                                whole ? 1 : 0, a_start, a_cnt, prod);
         device_exclusive_scan<LoadU64, uint64_t>(LoadU64{prod}, nk, prod_off, scan_tmp, s);
         const uint64_t nblocks = (count + kMulPerBlock - 1) / kMulPerBlock;
+        dbg_sync(s, "panel columns + scan");
         tm.begin(PH_MUL_K);
         multiply_kernel<T><<<(unsigned)nblocks, kMulThreads, 0, s>>>(a_vals, b_colidx, b_vals, b_rowptr, chunk_off, e0,
                                                                      a_start, a_cnt, prod_off, k0, nk, count, base, stage);
         tm.end(PH_MUL_K);
+        dbg_sync(s, "multiply");
         res->info.multiply_launches++;
     }
 };
