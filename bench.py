@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--dtype", default="f64", choices=["f32", "f64"])
     ap.add_argument("--partial-capacity", type=int, default=0)
+    ap.add_argument("--algorithm", default="outer", choices=["outer", "rowwise"],
+                    help="outer (default, the metric's algorithm) or the row-wise variant for rows that fit one merge tile")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="time the CPU reference on a k-slab (rank 0, N=1)")
     ap.add_argument("--cpu-partials", type=float, default=2.5e8, help="partial products in the CPU sample slab")
     ap.add_argument("--stream-output", action="store_true",
@@ -199,6 +201,7 @@ def main():
     nnz_a = int(csr[0][-1])
     torch.cuda.synchronize()
     ctx = S.Context(dev_index)
+    ctx.algorithm = args.algorithm
     ptrs = [t.data_ptr() for t in (*csc, *csr)]
 
     if not use_dist and args.stream_output:
@@ -303,7 +306,7 @@ def main():
             "config": {"workload": (f"R-MAT scale-{args.scale} edge-factor-{args.edge_factor} (a,b,c,d)={abcd} seed {args.seed}, "
                                     f"duplicates removed, self-product C=A*A, CSC x CSR -> CSR") if args.workload == "rmat" else
                                    "web-Google-shaped synthetic pattern matrix (916428 vertices, power-law degrees), self-product",
-                       "n": n, "nnz_a": nnz_a, "partials": P, "nnz_c": nnz_c,
+                       "n": n, "nnz_a": nnz_a, "partials": P, "nnz_c": nnz_c, "algorithm": args.algorithm,
                        "parallelism": ("single GPU, output streamed panel by panel (never resident)" if args.stream_output else "single GPU") if world == 1 else (
                            f"k-sharded over {world} GPUs + RCCL all-to-all of partial CSRs" if args.shard == "k" else
                            f"output rows sharded over {world} GPUs (operands replicated, result row-sharded, no exchange)")},

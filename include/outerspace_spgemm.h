@@ -56,6 +56,13 @@ typedef enum osp_status {
 typedef enum osp_dtype { OSP_F32 = 0, OSP_F64 = 1 } osp_dtype_t;
 typedef enum osp_memspace { OSP_HOST = 0, OSP_DEVICE = 1 } osp_memspace_t;
 
+/* Two formulations of the same product (identical results, bit for bit):
+ *   OSP_ALGO_OUTER    outer products, staged in HBM and merged (the reference's algorithm, SimSpGEMM.cpp:265-297)
+ *   OSP_ALGO_ROWWISE  output rows whose partial products fit one merge tile are formed row by row inside the merge
+ *                     kernel and never staged (the reference's row-wise alternative, SimSpGEMM.cpp:247-263); longer
+ *                     rows still take the outer-product path */
+typedef enum osp_algorithm { OSP_ALGO_OUTER = 0, OSP_ALGO_ROWWISE = 1 } osp_algorithm_t;
+
 typedef struct osp_context_s *osp_context_t;
 typedef struct osp_result_s *osp_result_t;
 
@@ -70,7 +77,8 @@ typedef struct osp_config {
     int row_shard_count;        /* `index` of `count` ranges balanced by partial products (count <= 1: all  */
                                 /* rows).  Every rank derives the same ranges from the operands alone: no   */
                                 /* communication.  The result then has row_end - row_begin rows.            */
-    int reserved[6];
+    int algorithm;              /* osp_algorithm_t (0 = outer product) */
+    int reserved[5];
 } osp_config_t;
 
 /* What one multiply did.  Times are device milliseconds measured with HIP events on the

@@ -26,7 +26,8 @@ class OspError(RuntimeError):
 
 class Config(C.Structure):
     _fields_ = [("validate", C.c_int), ("partial_capacity", C.c_uint64), ("k_begin", C.c_uint64),
-                ("k_end", C.c_uint64), ("row_shard_index", C.c_int), ("row_shard_count", C.c_int), ("reserved", C.c_int * 6)]
+                ("k_end", C.c_uint64), ("row_shard_index", C.c_int), ("row_shard_count", C.c_int), ("algorithm", C.c_int),
+                ("reserved", C.c_int * 5)]
 
 
 class ResultInfo(C.Structure):

@@ -349,6 +349,7 @@ template <class T> struct MergeIO {
     const uint64_t *row_off; uint64_t r0, r1, base;
     int64_t *c_rowptr; uint32_t *c_col; T *c_val;  // output (c_rowptr indexed by absolute row id)
     const uint64_t *out_in; uint64_t *out_out;    // entries written before / after this call (device)
+    ChunkTable<T> ct{};                           // row-wise variant: rows that fit a tile are computed in the tile kernel
 };
 
 struct TilePlan {
@@ -531,9 +532,15 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
     dbg_sync(s, "tile planning, splits, over-long segments");
     tm.begin(PH_MERGE_K);
     // persistent workgroups: as many as the LDS lets run at once
-    const uint32_t merge_grid = ctx->cus * (uint32_t)merge_wgs_per_cu<T, kMergeThreads, TileCap<T>::value>();
-    merge_tiles_kernel<T, kMergeThreads><<<std::min<uint32_t>(ntot, merge_grid), kMergeThreads, 0, s>>>(
-        desc, ntot, lv, colbits, tile_status, ticket, io.out_in, io.c_col, io.c_val, io.out_out);
+    if (io.ct.enabled) {
+        const uint32_t rw_grid = ctx->cus * (uint32_t)merge_wgs_per_cu<T, kMergeThreads, TileCap<T>::value, kMergeMaxWgs, 64>();
+        merge_tiles_kernel<T, kMergeThreads, 64><<<std::min<uint32_t>(ntot, rw_grid), kMergeThreads, 0, s>>>(
+            desc, ntot, lv, colbits, tile_status, ticket, io.out_in, io.c_col, io.c_val, io.out_out, io.ct);
+    } else {
+        const uint32_t merge_grid = ctx->cus * (uint32_t)merge_wgs_per_cu<T, kMergeThreads, TileCap<T>::value>();
+        merge_tiles_kernel<T, kMergeThreads><<<std::min<uint32_t>(ntot, merge_grid), kMergeThreads, 0, s>>>(
+            desc, ntot, lv, colbits, tile_status, ticket, io.out_in, io.c_col, io.c_val, io.out_out);
+    }
     tm.end(PH_MERGE_K);
     dbg_sync(s, "merge tiles");
     res->info.merge_launches++;
@@ -558,7 +565,7 @@ template <class T>
 static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_t M_all, uint64_t N,
                            const uint64_t *d_row_off,
                            uint64_t P, uint64_t cap_cfg, PhaseTimer &tm, uint64_t r_lo = 0, uint64_t r_hi = ~0ull,
-                           uint64_t off_lo = 0, const PanelSink *sink = nullptr) {
+                           uint64_t off_lo = 0, const PanelSink *sink = nullptr, const ChunkTable<T> *ct = nullptr) {
     // output rows [r_lo, r_hi) only (row-sharded multi-GPU mode); P = their partial products, off_lo = row_off[r_lo]
     if (r_hi == ~0ull) r_hi = M_all;
     const uint64_t M = r_hi - r_lo;
@@ -673,6 +680,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
             tm.begin(PH_MERGE);
             OSP_HIP(hipMemsetAsync(cells, 0, 2 * sizeof(uint64_t), s));
             MergeIO<T> io{stage, d_row_off, r0, r1, base, prow - r0, c_col, c_val, cells, cells + 1};
+            if (ct) io.ct = *ct;
             merge_panel<T>(ctx, res, tm, io, colbits);
             tm.end(PH_MERGE);
             const uint64_t nnz_p = d2h(cells + 1, s);  // synchronises: the panel is complete
@@ -697,6 +705,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         // ---- merge ----
         tm.begin(PH_MERGE);
         MergeIO<T> io{stage, d_row_off, r0, r1, base, res->rowptr - r_lo, c_col, c_val, out_nnz + p, out_nnz + p + 1};
+        if (ct) io.ct = *ct;
         merge_panel<T>(ctx, res, tm, io, colbits);
         tm.end(PH_MERGE);
     }
@@ -728,8 +737,10 @@ template <class T> struct OuterProducer : Producer<T> {
     uint64_t k0, k1; int64_t e0;
     const uint64_t *chunk_off;
     int64_t *a_start; uint32_t *a_cnt; uint64_t *prod; uint64_t *prod_off; uint64_t *scan_tmp;
+    bool nothing_staged = false;  // row-wise variant and no row is longer than a tile: the tile kernel does it all
     void produce(uint64_t r0, uint64_t r1, bool whole, uint64_t base, uint64_t count, Part<T> *stage,
                  PhaseTimer &tm) override {
+        if (nothing_staged) return;
         hipStream_t s = ctx->stream;
         const uint64_t nk = k1 - k0;
         panel_columns_kernel<<<grid_for(nk, 256), 256, 0, s>>>(a_colptr, a_rowidx, b_rowptr, k0, nk, (uint32_t)r0, r1,
@@ -886,25 +897,45 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     uint64_t *row_off = sc.get<uint64_t>(M + 1);
     uint64_t *chunk_off = sc.get<uint64_t>(nnz);
     uint64_t P = 0;
+    // Row-wise variant (cfg.algorithm): rows of up to one tile of partial products are computed inside the tile kernel
+    // from the chunk table; B's offsets must fit 32 bits for it (otherwise the outer-product path runs as usual)
+    // (debugging aid: OSP_ALGORITHM=rowwise|outer overrides the configuration, so that whole test suites can run either way)
+    const char *algo_env = getenv("OSP_ALGORITHM");
+    const int algo = algo_env ? (strcmp(algo_env, "rowwise") == 0 ? OSP_ALGO_ROWWISE : OSP_ALGO_OUTER) : cfg.algorithm;
+    if (algo != OSP_ALGO_OUTER && algo != OSP_ALGO_ROWWISE) throw Error(OSP_ERR_ARG, "unknown algorithm");
+    const bool rowwise = algo == OSP_ALGO_ROWWISE && nnz && (uint64_t)nnz_b < 0xffffffffull && nnz < 0xffffffffull;
+    ChunkTable<T> ct{};
+    uint32_t n_long_rows = 1;
     if (nnz == 0) {
         OSP_HIP(hipMemsetAsync(row_off, 0, (M + 1) * sizeof(uint64_t), s));
     } else {
         Scratch ss(ctx);
+        Scratch &keep = rowwise ? sc : ss;  // the chunk table outlives the symbolic phase
         uint32_t *ka = ss.get<uint32_t>(nnz), *pa = ss.get<uint32_t>(nnz), *kb = ss.get<uint32_t>(nnz), *pb = ss.get<uint32_t>(nnz);
-        uint32_t *rows_sorted = ss.get<uint32_t>(nnz), *perm = ss.get<uint32_t>(nnz), *w_sorted = ss.get<uint32_t>(nnz);
+        uint32_t *rows_sorted = ss.get<uint32_t>(nnz), *perm = keep.get<uint32_t>(nnz), *w_sorted = ss.get<uint32_t>(nnz);
+        uint32_t *bs_sorted = rowwise ? keep.get<uint32_t>(nnz) : nullptr;
+        uint32_t *rowfirst = keep.get<uint32_t>(M + 1);
         uint32_t *hist = ss.get<uint32_t>(rs_hist_entries(nnz));
         uint32_t *hist_tmp = ss.get<uint32_t>(scan_scratch_entries(rs_hist_entries(nnz)));
-        uint64_t *offs_sorted = ss.get<uint64_t>(nnz + 1);
-        uint64_t *scan_tmp = ss.get<uint64_t>(scan_scratch_entries(nnz));
+        uint64_t *offs_sorted = keep.get<uint64_t>(nnz + 1);
+        uint64_t *scan_tmp = ss.get<uint64_t>(scan_scratch_entries(std::max<uint64_t>(nnz, M + 1)));
         // (row, k) order of A's non-zeros; the last sort pass also looks up each chunk's length
         uint32_t *w = ss.get<uint32_t>(nnz);
-        sym_chunk_len_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(a_colptr, b_rowptr, k0, k1, e0, nnz, w);
+        uint32_t *bs = rowwise ? ss.get<uint32_t>(nnz) : nullptr;
+        sym_chunk_len_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(a_colptr, b_rowptr, k0, k1, e0, nnz, w, bs);
         device_sort_rows<SymEpilogue>(a_rowidx + e0, nnz, std::max(1, bits_for(M)), ka, pa, kb, pb, hist, hist_tmp,
-                                      SymEpilogue{w, rows_sorted, perm, w_sorted}, s);
+                                      SymEpilogue{w, bs, rows_sorted, perm, w_sorted, bs_sorted}, s);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{w_sorted}, nnz, offs_sorted, scan_tmp, s);
-        sym_scatter_offsets_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(perm, offs_sorted, nnz, chunk_off);
-        sym_row_offsets_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(rows_sorted, offs_sorted, nnz, M, row_off);
+        sym_row_offsets_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(rows_sorted, offs_sorted, nnz, M, row_off, rowfirst);
+        const uint64_t rw_cap = rowwise ? (uint64_t)TileCap<T>::value : 0ull;
+        sym_scatter_offsets_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(perm, offs_sorted, rows_sorted, row_off, rw_cap, nnz, chunk_off);
         P = d2h(offs_sorted + nnz, s);
+        if (rowwise) {
+            ct = ChunkTable<T>{offs_sorted, bs_sorted, perm, rowfirst, a_vals + e0, b_colidx, b_vals, (uint32_t)rw_cap, 1u};
+            uint32_t *flag_scan = ss.get<uint32_t>(M + 1);
+            device_exclusive_scan<HeavyRowFlag, uint32_t>(HeavyRowFlag{row_off, 0, (uint32_t)rw_cap}, M, flag_scan, (uint32_t *)scan_tmp, s);
+            n_long_rows = d2h(flag_scan + M, s);
+        }
     }
     tm.end(PH_SYM);
     res->info.partials = P;
@@ -918,10 +949,12 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     prod.a_start = sc.get<int64_t>(nk); prod.a_cnt = sc.get<uint32_t>(nk);
     prod.prod = sc.get<uint64_t>(nk); prod.prod_off = sc.get<uint64_t>(nk + 1);
     prod.scan_tmp = sc.get<uint64_t>(scan_scratch_entries(nk));
+    prod.nothing_staged = rowwise && n_long_rows == 0;
 
     // row-sharded: A holds this rank's rows only, so the staging offsets start at 0 at r_lo and P is the shard's count
     const uint64_t off_lo = 0, P_rows = P;
-    merge_pipeline<T>(ctx, res, prod, M, N, row_off, P_rows, cfg.partial_capacity, tm, r_lo, r_hi, off_lo, sink);
+    merge_pipeline<T>(ctx, res, prod, M, N, row_off, P_rows, cfg.partial_capacity, tm, r_lo, r_hi, off_lo, sink,
+                      rowwise ? &ct : nullptr);
 
     OSP_HIP(hipEventRecord(ev1, s));
     OSP_HIP(hipStreamSynchronize(s));

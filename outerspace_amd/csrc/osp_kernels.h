@@ -128,21 +128,43 @@ struct LoadGatherW {  // w in row order
     __device__ uint64_t operator()(uint64_t t) const { return w[perm[t]]; }
 };
 
-// chunk_off[perm[t]] = offs_sorted[t]
-__global__ void sym_scatter_offsets_kernel(const uint32_t *perm, const uint64_t *offs_sorted,
-                                           uint64_t nnz, uint64_t *chunk_off) {
+// ---- the row-wise variant -----------------------------------------------------------
+// cfg.algorithm = OSP_ALGO_ROWWISE: rows whose partial products fit one merge tile are never staged.  The tile kernel
+// computes them itself, row by row, from A's row (the chunk table below: one entry per non-zero A[i,k]) and the B rows
+// it touches -- Gustavson's formulation, with the tile's sort + run sums in place of a hash accumulator, so that
+// values stay bit-identical -- and the multiply phase skips those rows (kChunkSkip).  Longer rows keep the
+// outer-product path: staged, split, merged.
+constexpr uint64_t kChunkSkip = ~0ull;  // chunk_off of a chunk the multiply phase must not write
+template <class T>
+struct ChunkTable {
+    const uint64_t *off;       // staging offset of chunk t (nnz + 1 entries), chunks in (row, k) order
+    const uint32_t *bs;        // first entry of the chunk's B row in b_colidx / b_vals
+    const uint32_t *perm;      // the chunk's A entry: position in a_vals (already offset to the k shard)
+    const uint32_t *rowfirst;  // first chunk of every row (M + 1 entries)
+    const T *a_vals;
+    const uint32_t *b_colidx;
+    const T *b_vals;
+    uint32_t cap;              // rows of up to `cap` partial products are computed row-wise
+    uint32_t enabled;
+};
+// chunk_off[perm[t]] = offs_sorted[t], or kChunkSkip for the chunks of rows computed row-wise
+__global__ void sym_scatter_offsets_kernel(const uint32_t *perm, const uint64_t *offs_sorted, const uint32_t *rows_sorted,
+                                           const uint64_t *row_off, uint64_t rowwise_cap, uint64_t nnz, uint64_t *chunk_off) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < nnz) chunk_off[perm[t]] = offs_sorted[t];
+    if (t >= nnz) return;
+    const uint32_t r = rows_sorted[t];
+    chunk_off[perm[t]] = (row_off[r + 1] - row_off[r]) <= rowwise_cap ? kChunkSkip : offs_sorted[t];
 }
 
 // row_off[i] = staging offset of row i's first partial product, arow[i] = index of its first
 // non-empty chunk, i in [0, M]
 __global__ void sym_row_offsets_kernel(const uint32_t *rows_sorted, const uint64_t *offs_sorted, uint64_t nnz, uint64_t M,
-                                       uint64_t *row_off) {
+                                       uint64_t *row_off, uint32_t *rowfirst) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > M) return;
     uint64_t t = lower_bound_dev(rows_sorted, 0, nnz, (uint64_t)i);
     row_off[i] = offs_sorted[t];  // offs_sorted has nnz+1 entries, [nnz] = P
+    rowfirst[i] = (uint32_t)t;    // row i's chunks are entries [rowfirst[i], rowfirst[i+1]) of the (row, k) order
 }
 struct LenGatherW {  // chunk length of the t-th A entry in (row, k) order
     const uint32_t *w;
@@ -231,8 +253,12 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
             for (uint64_t jb = j0; jb <= j1; jb += kWave) {
                 const uint64_t jm = jb + lane;
                 T av_l = 0;
-                uint64_t off_l = 0;
-                if (jm <= j1) { av_l = a_vals[as + jm]; off_l = chunk_off[as + jm - (uint64_t)e0] - base; }
+                uint64_t off_l = kChunkSkip;
+                if (jm <= j1) {
+                    av_l = a_vals[as + jm];
+                    const uint64_t raw = chunk_off[as + jm - (uint64_t)e0];
+                    off_l = raw == kChunkSkip ? kChunkSkip : raw - base;
+                }
                 const uint32_t cj = (uint32_t)min((uint64_t)kWave, j1 - jb + 1);
                 for (uint32_t l0 = 0; l0 < nb; l0 += kWave) {
                     const uint32_t l = l0 + lane;
@@ -243,7 +269,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                         const uint64_t j = jb + q;
                         const T av = wave_bcast(av_l, q);
                         const uint64_t off = wave_bcast(off_l, q);
-                        const bool ok = in && !(j == j0 && l < la) && !(j == j1 && l >= lb);
+                        const bool ok = in && off != kChunkSkip && !(j == j0 && l < la) && !(j == j1 && l >= lb);
                         if (ok) stage[off + l] = Part<T>{bc, av * bv};
                     }
                 }
@@ -261,8 +287,8 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                 bool ok = in && j <= j1 && !(j == j0 && l < la) && !(j == j1 && l >= lb);
                 if (ok) {
                     const uint64_t e = as + j;
-                    const uint64_t off = chunk_off[e - (uint64_t)e0] - base;
-                    stage[off + l] = Part<T>{bc, a_vals[e] * bv};
+                    const uint64_t raw = chunk_off[e - (uint64_t)e0];
+                    if (raw != kChunkSkip) stage[raw - base + l] = Part<T>{bc, a_vals[e] * bv};
                 }
             }
         }
@@ -539,24 +565,29 @@ __device__ unsigned long long osp_merge_prof[16];
 // round trip instead of a chain of five.
 // workgroups of NT threads that fit one CU's 160 KiB of LDS -> waves per SIMD the register budget must allow
 constexpr int kMergeMaxWgs = 5;  // per CU (measured: five workgroups at <= 102 registers, a few spilled, beat four at 120)
-template <class T, int NT, int CAP, int MAXWG = kMergeMaxWgs>
+template <class T, int NT, int CAP, int MAXWG = kMergeMaxWgs, int ABL = 0>
 constexpr int merge_wgs_per_cu() {
-    const int wgs = (160 * 1024) / (int)(sizeof(MergeSmem<T, NT, CAP>) + 64);
+    // (mode 64, row-wise tiles, keeps the values of a tile in LDS: one more array)
+    const int wgs = (160 * 1024) / (int)(sizeof(MergeSmem<T, NT, CAP>) + ((ABL & 64) ? CAP * sizeof(T) : 0) + 64);
     return wgs > MAXWG ? MAXWG : wgs;
 }
-template <class T, int NT, int CAP, int MAXWG = kMergeMaxWgs>
+template <class T, int NT, int CAP, int MAXWG = kMergeMaxWgs, int ABL = 0>
 constexpr int merge_waves_per_simd() {
-    const int w = merge_wgs_per_cu<T, NT, CAP, MAXWG>() * NT / 256;
+    const int w = merge_wgs_per_cu<T, NT, CAP, MAXWG, ABL>() * NT / 256;
     return w > 8 ? 8 : (w < 1 ? 1 : w);
 }
 template <class T, int NT, int ABL = 0, int CAP = TileCap<T>::value, int MAXWG = kMergeMaxWgs>
-__global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG>())) void merge_tiles_kernel(
+__global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>())) void merge_tiles_kernel(
     const TileDesc *__restrict__ desc, uint32_t ntiles, const MergeLevels<T> lvl, int colbits, uint64_t *tile_status,
     uint32_t *ticket, const uint64_t *__restrict__ out_base_p, uint32_t *__restrict__ c_col, T *__restrict__ c_val,
-    uint64_t *__restrict__ out_end_p) {
+    uint64_t *__restrict__ out_end_p, const ChunkTable<T> ct = ChunkTable<T>{}) {
     __shared__ MergeSmem<T, NT, CAP> sm;
     __shared__ TileDesc s_dnext;
     __shared__ uint32_t s_tnext;
+    // Mode 64 (row-wise variant): level-0 tiles -- rows that fit a tile -- are not read from the staging buffer; their
+    // partial products are computed here from the chunk table, and their values stay in this array
+    constexpr bool ROWWISE = (ABL & 64) != 0;
+    __shared__ T rwval[ROWWISE ? CAP : 1];
     constexpr int kTileCap = CAP;
     constexpr int NW = NT / kWave;
     constexpr int LPT = (kTileCap + NT - 1) / NT;
@@ -580,10 +611,11 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG>())) vo
     uint64_t ro = 0;
     PartWords<T> lrec[LPT];  // raw: unpacked at staging time, so the loads stay in flight together
     auto request = [&](const TileDesc &dd, bool ok) {
-        const bool fetch = ok && dd.n <= (uint32_t)kTileCap;
+        bool fetch = ok && dd.n <= (uint32_t)kTileCap;
         ro = 0;
         const Part<T> *__restrict__ stage = lvl.stage[dd.lvl];
         if (fetch && tid <= dd.nr) ro = lvl.row_off[dd.lvl][dd.ra + tid];
+        if (ROWWISE && dd.lvl == 0) fetch = false;  // nothing was staged for these rows
 #pragma unroll
         for (int q = 0; q < LPT; q++) {
             const uint32_t i = tid + q * NT;
@@ -651,41 +683,115 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG>())) vo
         // until pass 0; the values stay in registers until the sort is over.
         uint32_t fresh = 0;
         uint32_t kq[LPT];
+        const bool rw_tile = ROWWISE && d.lvl == 0;
+        if (rw_tile) {
+            if constexpr (ROWWISE) {
+                // Row-wise tile: the partial products of rows [ra, ra+nr) are formed here.  The rows' chunks (one per
+                // non-zero A[i,k], in (row, k) order -- the staging order) are taken kRwGroup at a time by a wave: lane q
+                // holds chunk q's start position, B row and A value; then the lanes walk the group's entries, each
+                // finding its chunk by bisecting the start positions with ds_bpermute.  Four steps of the walk are in
+                // flight at once (their gathers from B are independent).
+                constexpr uint32_t kRwSteps = 6, kRwUnroll = 4;
+                const uint32_t c0 = ct.rowfirst[ra], c1 = ct.rowfirst[ra + nr];
+                // chunks per group: few when they are long (so that all waves get some), a wave-full when they are tiny
+                const uint32_t kRwGroup = (n < 6u * (c1 - c0)) ? 64u : 16u;
+                for (uint32_t cb = c0 + w * kRwGroup; cb < c1; cb += NW * kRwGroup) {
+                    const uint32_t c = cb + lane;
+                    const bool cv = lane < kRwGroup && c < c1;
+                    const uint64_t o0 = cv ? ct.off[c] : 0ull, o1 = cv ? ct.off[c + 1] : 0ull;
+                    const uint32_t st = cv ? (uint32_t)(o0 - base - s) : n;  // lanes past the end: behind every entry
+                    const uint32_t en = cv ? (uint32_t)(o1 - base - s) : n;
+                    const uint32_t bsv = cv ? ct.bs[c] : 0u;
+                    const T av = cv ? ct.a_vals[ct.perm[c]] : T(0);
+                    uint32_t lrow = 0;
+                    {
+                        uint32_t lo = 0, hi = nr;  // last r with rowo[r] <= st
+                        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sm.rowo[mid] <= st) lo = mid; else hi = mid; }
+                        lrow = colbits < 32 ? (lo << colbits) : 0u;
+                    }
+                    const uint32_t nvalid = min(kRwGroup, c1 - cb);
+                    const uint32_t gbeg = wave_bcast(st, 0u), gend = wave_bcast(en, nvalid - 1);
+                    for (uint32_t ib0 = gbeg; ib0 < gend; ib0 += kRwUnroll * kWave) {
+                        uint32_t bcol[kRwUnroll], crow[kRwUnroll];
+                        T bval[kRwUnroll], cav[kRwUnroll];
 #pragma unroll
-        for (int q = 0; q < LPT; q++) {
-            const uint32_t i = tid + q * NT;
-            kq[q] = 0;
-            if (i < n) {
-                if (relkey) {
-                    kq[q] = lrec[q].col() - cbase;
-                } else {
-                    uint32_t lo = 0, hi = nr;  // last r with rowo[r] <= i
-                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sm.rowo[mid] <= i) lo = mid; else hi = mid; }
-                    kq[q] = (colbits < 32 ? (lo << colbits) : 0u) | lrec[q].col();
+                        for (uint32_t u = 0; u < kRwUnroll; u++) {
+                            const uint32_t i = ib0 + u * kWave + lane;
+                            uint32_t lo = 0, hi = kRwGroup;  // last lane whose chunk starts at or before i
+#pragma unroll
+                            for (uint32_t step = 0; step < kRwSteps; step++) {
+                                const uint32_t mid = (lo + hi) >> 1;
+                                const uint32_t sv = (uint32_t)__shfl((int)st, (int)mid);
+                                if (sv <= i) lo = mid; else hi = mid;
+                            }
+                            const uint32_t cst = (uint32_t)__shfl((int)st, (int)lo);
+                            const uint32_t cbs = (uint32_t)__shfl((int)bsv, (int)lo);
+                            crow[u] = (uint32_t)__shfl((int)lrow, (int)lo);
+                            cav[u] = __shfl(av, (int)lo);
+                            const uint32_t b = i < gend ? cbs + (i - cst) : 0u;  // clamped, branch-free: loads stay in flight
+                            bcol[u] = ct.b_colidx[b];
+                            bval[u] = ct.b_vals[b];
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < kRwUnroll; u++) {
+                            const uint32_t i = ib0 + u * kWave + lane;
+                            if (i < gend) {
+                                const uint32_t key = crow[u] | bcol[u];
+                                sm.key0[i] = key;
+                                rwval[i] = cav[u] * bval[u];
+                                if (early) {
+                                    uint32_t h = (uint32_t)(((uint64_t)(key * 2654435761u) * HS) >> 32);
+                                    uint32_t old = atomicCAS(&htab[h], 0xffffffffu, key);
+                                    while (old != 0xffffffffu && old != key) {
+                                        h = (h + 1 == HS) ? 0u : h + 1;
+                                        old = atomicCAS(&htab[h], 0xffffffffu, key);
+                                    }
+                                    fresh += old == 0xffffffffu;
+                                }
+                            }
+                        }
+                    }
                 }
-                sm.key0[i] = kq[q];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < LPT; q++) {
+                const uint32_t i = tid + q * NT;
+                kq[q] = 0;
+                if (i < n) {
+                    if (relkey) {
+                        kq[q] = lrec[q].col() - cbase;
+                    } else {
+                        uint32_t lo = 0, hi = nr;  // last r with rowo[r] <= i
+                        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sm.rowo[mid] <= i) lo = mid; else hi = mid; }
+                        kq[q] = (colbits < 32 ? (lo << colbits) : 0u) | lrec[q].col();
+                    }
+                    sm.key0[i] = kq[q];
+                }
+            }
+            if (early) {
+                // first probes of all the thread's keys go out together; only collisions with a different key walk on
+                uint32_t hq[LPT], oq[LPT];
+#pragma unroll
+                for (int q = 0; q < LPT; q++) {
+                    hq[q] = (uint32_t)(((uint64_t)(kq[q] * 2654435761u) * HS) >> 32);
+                    oq[q] = kq[q];
+                    if (tid + q * NT < n) oq[q] = atomicCAS(&htab[hq[q]], 0xffffffffu, kq[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < LPT; q++) {
+                    if (tid + q * NT < n) {
+                        uint32_t old = oq[q], h = hq[q];
+                        while (old != 0xffffffffu && old != kq[q]) {
+                            h = (h + 1 == HS) ? 0u : h + 1;
+                            old = atomicCAS(&htab[h], 0xffffffffu, kq[q]);
+                        }
+                        fresh += old == 0xffffffffu;
+                    }
+                }
             }
         }
         if (early) {
-            // first probes of all the thread's keys go out together; only collisions with a different key walk on
-            uint32_t hq[LPT], oq[LPT];
-#pragma unroll
-            for (int q = 0; q < LPT; q++) {
-                hq[q] = (uint32_t)(((uint64_t)(kq[q] * 2654435761u) * HS) >> 32);
-                oq[q] = kq[q];
-                if (tid + q * NT < n) oq[q] = atomicCAS(&htab[hq[q]], 0xffffffffu, kq[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < LPT; q++) {
-                if (tid + q * NT < n) {
-                    uint32_t old = oq[q], h = hq[q];
-                    while (old != 0xffffffffu && old != kq[q]) {
-                        h = (h + 1 == HS) ? 0u : h + 1;
-                        old = atomicCAS(&htab[h], 0xffffffffu, kq[q]);
-                    }
-                    fresh += old == 0xffffffffu;
-                }
-            }
             const uint32_t wsum = wave_reduce_sum(fresh);
             if (lane == 0 && wsum) atomicAdd(&sm.hcount, wsum);
             __syncthreads();
@@ -772,14 +878,14 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG>())) vo
         }
         uint32_t *skey = sm.key(cur);   // sorted keys and their staging positions
         uint16_t *spos = sm.pos(cur);
-        T *sval = sm.vals(cur);         // the 8 bytes per entry beside them: values by staging position
+        T *sval = rw_tile ? rwval : sm.vals(cur);  // the 8 bytes per entry beside them: values by staging position
         if (npass == 0) {  // nothing was sorted (empty tile): the payload is still implicit
             for (uint32_t i = tid; i < n; i += NT) spos[i] = (uint16_t)i;
         }
         // the values: read again (the tile went through L2 a few microseconds ago) rather than held in 18 registers
         // through the sort -- that is what lets five workgroups per CU run without spilling.  The barriers inside the
         // scan below order the LDS writes before the run sums.
-        {
+        if (!rw_tile) {
             const Part<T> *__restrict__ stg = lvl.stage[d.lvl];
             T vq[LPT];
 #pragma unroll

@@ -194,21 +194,24 @@ __global__ void ingest_ptr_kernel(const uint32_t *seg_sorted, uint64_t n, uint64
 // (The chunk lengths are looked up in CSC order beforehand -- sym_chunk_len_kernel -- where neighbouring
 // threads share a column; doing the column search here, in row order, cost 7.5 ms instead of 0.4.)
 struct SymEpilogue {
-    const uint32_t *w;  // chunk length per A entry, CSC order
-    uint32_t *rows_sorted, *perm, *w_sorted;
+    const uint32_t *w;   // chunk length per A entry, CSC order
+    const uint32_t *bs;  // first entry of its B row, CSC order
+    uint32_t *rows_sorted, *perm, *w_sorted, *bs_sorted;
     __device__ void operator()(uint64_t t, uint32_t row, uint32_t pos) const {
         rows_sorted[t] = row;
         perm[t] = pos;
         w_sorted[t] = w[pos];
+        if (bs_sorted) bs_sorted[t] = bs[pos];  // (row-wise variant only)
     }
 };
-// w[t] = nnz(B[k,:]) for the t-th non-zero of A's shard (CSC order, column k)
+// w[t] = nnz(B[k,:]), bs[t] = b_rowptr[k] for the t-th non-zero of A's shard (CSC order, column k)
 __global__ void sym_chunk_len_kernel(const int64_t *a_colptr, const int64_t *b_rowptr, uint64_t k0, uint64_t k1, int64_t e0,
-                                     uint64_t nnz, uint32_t *w) {
+                                     uint64_t nnz, uint32_t *w, uint32_t *bs) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nnz) return;
     const uint64_t k = upper_bound_dev(a_colptr, k0, k1 + 1, e0 + (int64_t)t) - 1;
     w[t] = (uint32_t)(b_rowptr[k + 1] - b_rowptr[k]);
+    if (bs) bs[t] = (uint32_t)b_rowptr[k];
 }
 
 }  // namespace osp

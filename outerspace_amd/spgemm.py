@@ -81,6 +81,9 @@ class CsrResult:
             pass
 
 
+ALGORITHMS = {"outer": 0, "rowwise": 1}  # osp_algorithm_t
+
+
 class Context:
     """One GPU + one HIP stream + a buffer pool (``osp_context_t``)."""
 
@@ -94,6 +97,8 @@ class Context:
             _lib.check(_lib.lib().osp_context_create_on_stream(device, C.c_void_p(stream), C.byref(h)))
         self._h = h
         self.device = device
+        #: "outer" (default) or "rowwise": which formulation the products of this context use (osp_config_t.algorithm)
+        self.algorithm = "outer"
 
     def close(self):
         if self._h is not None:
@@ -126,6 +131,7 @@ class Context:
             cfg.k_begin, cfg.k_end = int(k_range[0]), int(k_range[1])
         if row_shard is not None:
             cfg.row_shard_index, cfg.row_shard_count = int(row_shard[0]), int(row_shard[1])
+        cfg.algorithm = ALGORITHMS[self.algorithm]
         return cfg
 
     def spgemm_csc_csr(self, M, K, N, a_colptr, a_rowidx, a_vals, b_rowptr, b_colidx, b_vals, *,

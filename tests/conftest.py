@@ -63,11 +63,21 @@ def port():
 
 
 @pytest.fixture(scope="session")
-def ctx():
-    """ONE library context (device 0: stream + buffer pool) for the whole session.  A context per test module meant
-    freeing every pooled device buffer and allocating the same addresses again a moment later; the intermittent GPU
-    memory faults of round 1 clustered right after such a hand-over, and a process normally keeps one context anyway."""
+def _ctx_shared():
     from outerspace_amd import spgemm as S
     c = S.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(params=["outer", "rowwise"])
+def ctx(request, _ctx_shared):
+    """Every test that multiplies runs once per formulation (osp_config_t.algorithm): outer product with staging, and the
+    row-wise variant that forms short rows inside the merge kernel.  Both must equal the oracle bit for bit.
+
+    ONE library context (device 0: stream + buffer pool) for the whole session.  A context per test module meant
+    freeing every pooled device buffer and allocating the same addresses again a moment later; the intermittent GPU
+    memory faults of round 1 clustered right after such a hand-over, and a process normally keeps one context anyway."""
+    _ctx_shared.algorithm = request.param
+    yield _ctx_shared
+    _ctx_shared.algorithm = "outer"
