@@ -78,6 +78,14 @@ def lib():
         raise ImportError(f"{LIB_PATH} not found: build it with `make -C outerspace_amd/csrc` "
                           "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
                           "There is no CPU fallback.")
+    # One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64 (SONAME libamdhip64.so.7, asked for as
+    # "libamdhip64.so" by torch's libraries): loaded first, it also satisfies this library's NEEDED entry; loaded second,
+    # the process ends up with two runtimes and torch reports "No HIP GPUs are available".  The package uses torch for
+    # device memory anyway, so it goes first when it is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
     L.osp_last_error_string.restype = C.c_char_p

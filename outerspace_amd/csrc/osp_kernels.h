@@ -691,10 +691,10 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                 // holds chunk q's start position, B row and A value; then the lanes walk the group's entries, each
                 // finding its chunk by bisecting the start positions with ds_bpermute.  Four steps of the walk are in
                 // flight at once (their gathers from B are independent).
-                constexpr uint32_t kRwSteps = 6, kRwUnroll = 4;
+                // (16 chunks per group keeps all four waves busy on tiles of ~100 chunks; a wave-full of 64 for tiles of tiny
+                // chunks was measured and made no difference)
+                constexpr uint32_t kRwGroup = 16, kRwSteps = 4, kRwUnroll = 4;
                 const uint32_t c0 = ct.rowfirst[ra], c1 = ct.rowfirst[ra + nr];
-                // chunks per group: few when they are long (so that all waves get some), a wave-full when they are tiny
-                const uint32_t kRwGroup = (n < 6u * (c1 - c0)) ? 64u : 16u;
                 for (uint32_t cb = c0 + w * kRwGroup; cb < c1; cb += NW * kRwGroup) {
                     const uint32_t c = cb + lane;
                     const bool cv = lane < kRwGroup && c < c1;
