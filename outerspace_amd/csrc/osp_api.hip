@@ -271,10 +271,55 @@ enum { PH_SYM = 0, PH_MUL = 1, PH_MERGE = 2, PH_COMPACT = 3, PH_MUL_K = 4, PH_ME
 
 // debugging aid: OSP_SYNC=1 waits for the stream at the marked points of a product and names them on stderr, so
 // that an asynchronous GPU fault is pinned to the step that caused it (the last name printed COMPLETED)
+#ifdef OSP_CHECK_DESC
+static unsigned long long *g_crumbs_host = nullptr;
+static void crumbs_init() {
+    if (g_crumbs_host) return;
+    if (hipHostMalloc((void **)&g_crumbs_host, 4096 * 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return;
+    memset(g_crumbs_host, 0, 4096 * 8 * sizeof(unsigned long long));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(osp_crumbs), &g_crumbs_host, sizeof(g_crumbs_host));
+}
+static void crumbs_dump(const char *what) {
+    if (!g_crumbs_host) return;
+    int shown = 0, hist[8] = {0};
+    for (int b = 0; b < 4096; b++) hist[g_crumbs_host[(size_t)b * 8] & 7u]++;
+    fprintf(stderr, "[osp] crumb phases: none %d, tile start %d, reload %d, output %d, tile done %d, kernel start %d, kernel end %d\n", hist[0], hist[1], hist[2], hist[3],
+            hist[4], hist[5], hist[7]);
+    for (int b = 0; b < 4096 && shown < 24; b++) {
+        const unsigned long long *p = g_crumbs_host + (size_t)b * 8;
+        const unsigned ph = (unsigned)(p[0] & 255u);
+        if (ph == 0 || ph == 7) continue;
+        fprintf(stderr, "[osp] crumb block %d: phase %u NT %llu ABL %llu tile %llu s %llu n %llu ra %llu | %llu %llu %llu\n", b, ph, (p[0] >> 8) & 0xffffu, p[0] >> 32,
+                p[1], p[2], p[3], p[7], p[4], p[5], p[6]);
+        shown++;
+    }
+    fprintf(stderr, "[osp] (%s: crumbs of workgroups that were inside a tile)\n", what);
+}
+#endif
 static inline void dbg_sync(hipStream_t s, const char *what) {
     static const bool on = getenv("OSP_SYNC") != nullptr;
     if (!on) return;
-    (void)hipStreamSynchronize(s);
+    const hipError_t e1 = hipStreamSynchronize(s), e2 = hipGetLastError();
+#ifdef OSP_CHECK_DESC
+    if (e1 != hipSuccess || e2 != hipSuccess) crumbs_dump(what);
+    else if (g_crumbs_host) memset(g_crumbs_host, 0, 4096 * 8 * sizeof(unsigned long long));
+#endif
+#ifdef OSP_CHECK_DESC
+    {
+        unsigned long long h[16] = {0};
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(osp_desc_bad), sizeof(h)) == hipSuccess && h[0]) {
+            fprintf(stderr, "[osp] DESCRIPTOR MISMATCH before '%s': %llu threads; first: tile %llu tid %llu s(lds) %llu s(mem) %llu n(lds) %llu n(mem) %llu lvl(lds) %llu block %llu NT %llu\n",
+                    what, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9]);
+            unsigned long long z[16] = {0};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(osp_desc_bad), z, sizeof(z));
+        }
+    }
+#endif
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        fprintf(stderr, "[osp] FAILED in: %s (%s)\n", what, hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        fflush(stderr);
+        throw Error(OSP_ERR_HIP, std::string("device error in phase: ") + what);
+    }
     fprintf(stderr, "[osp] ok: %s\n", what);
     fflush(stderr);
 }
@@ -394,6 +439,9 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
     Scratch sc(ctx);
     constexpr uint32_t kCap = (uint32_t)TileCap<T>::value;
     const uint32_t max_rows = (uint32_t)std::min<uint64_t>(kTileMaxRows, colbits >= 32 ? 1ull : (1ull << (32 - colbits)));
+#ifdef OSP_CHECK_DESC
+    crumbs_init();
+#endif
     const uint64_t r0 = io.r0, r1 = io.r1, base = io.base;
     const TilePlan p0 = plan_tiles(ctx, sc, io.row_off, r0, r1, base, kCap, max_rows, nullptr);
     res->info.light_tiles += p0.ntiles - p0.nlong;
@@ -444,6 +492,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         // rows up to kSplitRowMax: one workgroup each (histogram, scan and scatter in one kernel)
         split_row_kernel<T><<<nlong, kSplitThreads, 0, s>>>(p0.long_rows, nlong, hbits, nstretch, vbase, hoff, io.row_off, base, colbits,
                                                             io.stage, qstage, vrow_off);
+        dbg_sync(s, "split: one-workgroup rows");
         if (nblocks) {  // longer rows: one workgroup per 4096-entry stretch, offsets from a device-wide scan
             split_count_kernel<<<(unsigned)nblocks, kSplitThreads, 0, s>>>(p0.long_rows, nlong, blkbase, hbase, hbits, nstretch, io.row_off,
                                                                          base, colbits, (const char *)io.stage, (uint32_t)sizeof(Part<T>), ghist);
@@ -451,10 +500,13 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
             split_scatter_kernel<T><<<(unsigned)nblocks, kSplitThreads, 0, s>>>(p0.long_rows, nlong, blkbase, hbase, hbits, nstretch,
                                                                               io.row_off, base, colbits, io.stage, ghist, hoff, qstage);
         }
+        dbg_sync(s, "split: stretch rows");
         split_vrows_kernel<<<grid_for(nvirt + 1, 256), 256, 0, s>>>(nlong, vbase, hbase, nstretch, ghist, hoff, nvirt, nh, vrow_off, vfirst);
         OSP_HIP(hipGetLastError());
+        dbg_sync(s, "split: segment offsets");
         // ---- tiles over the segments; a tile never spans two long rows ----
         p1 = plan_tiles(ctx, sc, vrow_off, 0, nvirt, 0, kCap, max_rows, vfirst);
+        dbg_sync(s, "tiles over the segments");
         vptr = (int64_t *)sc.get<uint64_t>(nvirt + 1);
         lv.stage[1] = qstage; lv.row_off[1] = vrow_off; lv.base[1] = 0; lv.c_rowptr[1] = vptr;
         if (p1.nlong) {
@@ -466,7 +518,10 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
             // by length: up to kBigTileCap -> one big LDS tile each, reduced in place; beyond -> global sort
             uint32_t *hscan = sc.get<uint32_t>((uint64_t)nseg_long + 1);
             uint64_t *sscan_tmp = sc.get<uint64_t>(scan_scratch_entries(nseg_long));  // NOT hscan_tmp: that one is sized for nlong
-            const SegHugeFlag hf{p1.long_rows, vrow_off, (uint32_t)kBigTileCap};
+            // (debugging aid: OSP_BIGTILE_CAP=0 sends every over-long segment down the global-sort path)
+            const uint32_t big_cap = getenv("OSP_BIGTILE_CAP") ? std::min<uint32_t>((uint32_t)strtoul(getenv("OSP_BIGTILE_CAP"), nullptr, 10), kBigTileCap)
+                                                                : (uint32_t)kBigTileCap;
+            const SegHugeFlag hf{p1.long_rows, vrow_off, big_cap};
             device_exclusive_scan<SegHugeFlag, uint32_t>(hf, nseg_long, hscan, (uint32_t *)sscan_tmp, s);
             const uint32_t nhuge = d2h(hscan + nseg_long, s), nmid = nseg_long - nhuge;
             uint32_t *huge_list = sc.get<uint32_t>(nhuge), *mid_list = sc.get<uint32_t>(nmid);
@@ -481,6 +536,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
                 merge_tiles_kernel<T, kBigTileThreads, 32, kBigTileCap><<<std::min<uint32_t>(nmid, bgrid), kBigTileThreads, 0, s>>>(
                     bdesc, nmid, lv, colbits, nullptr, bticket, nullptr, nullptr, nullptr, nullptr);
             }
+            dbg_sync(s, "over-long segments: big in-place tiles");
             if (nhuge) {
                 // one output entry fed by more products than any tile holds: global stable sort on (segment, col),
                 // run sums in place in the second buffer
@@ -506,6 +562,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
                                                                          nhuge, vrow_off, 0, colbits, qstage);
                 heavy_rows_kernel<<<grid_for(nhuge, 256), 256, 0, s>>>(huge_list, soff, nhuge, headscan, seg_nnz);
             }
+            dbg_sync(s, "over-long segments: global sort");
             heavy_src_inplace_kernel<<<grid_for(nseg_long, 256), 256, 0, s>>>(p1.long_rows, nseg_long, vrow_off, 0, seg_src);
         }
         lv.heavy_nnz[1] = seg_nnz;
@@ -520,6 +577,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
                                                                            nlong, tb, colbits, hbits, vbase, desc);
         tile_desc_kernel<(int)kCap><<<grid_for(p1.ntiles, 256), 256, 0, s>>>(p1.tile_rows, p1.ntiles, nvirt, vrow_off, 0, 1u, j0, extra,
                                                                            nlong, tb, colbits, hbits, vbase, desc);
+        dbg_sync(s, "tile chain");
     } else {
         desc = sc.get<TileDesc>(ntot);
         tile_desc_kernel<(int)kCap><<<grid_for(p0.ntiles, 256), 256, 0, s>>>(p0.tile_rows, p0.ntiles, r1, io.row_off, base, 0u, nullptr,

@@ -540,6 +540,28 @@ __global__ void chain_finish_kernel(const uint32_t *heavy_rows, uint32_t nlong, 
     if (h == 0) c_rowptr[r_end] = (int64_t)*out_end;
 }
 
+// Debug build (`make debug`, -DOSP_CHECK_DESC; compiled out of the library otherwise).  Every thread compares the tile
+// descriptor it got through LDS with the one in global memory, and every workgroup leaves breadcrumbs -- phase, tile
+// and the descriptor it is working on -- in PINNED HOST memory, which the host can still read after a device fault
+// (dbg_sync prints them under OSP_SYNC=1).  This is what found round 1's intermittent fault: workgroups at "kernel
+// start" holding tile numbers beyond the tile count and garbage descriptors.
+#ifdef OSP_CHECK_DESC
+__device__ unsigned long long osp_desc_bad[16];
+#define OSP_DESC_CHECK(t_, d_) do { if ((t_) < ntiles) { const TileDesc g_ = desc[(t_)]; \
+    if (g_.s != (d_).s || g_.n != (d_).n || g_.ra != (d_).ra || g_.nr != (d_).nr || g_.lvl != (d_).lvl) { \
+        if (atomicAdd(&osp_desc_bad[0], 1ull) == 0) { osp_desc_bad[1] = (t_); osp_desc_bad[2] = tid; osp_desc_bad[3] = (d_).s; osp_desc_bad[4] = g_.s; \
+            osp_desc_bad[5] = (d_).n; osp_desc_bad[6] = g_.n; osp_desc_bad[7] = (d_).lvl; osp_desc_bad[8] = blockIdx.x; osp_desc_bad[9] = NT; } \
+        (d_) = g_; } } } while (0)
+// breadcrumbs in pinned host memory (readable after a device fault): what every workgroup was doing last
+__device__ unsigned long long *osp_crumbs;
+#define OSP_CRUMB(ph_, a_, b_, c_) do { if (tid == 0 && osp_crumbs) { volatile unsigned long long *p_ = osp_crumbs + (size_t)(blockIdx.x & 4095u) * 8u; \
+    p_[1] = t; p_[2] = d.s; p_[3] = d.n; p_[4] = (a_); p_[5] = (b_); p_[6] = (c_); p_[7] = d.ra; \
+    p_[0] = (unsigned long long)(ph_) | ((unsigned long long)NT << 8) | ((unsigned long long)ABL << 32); __threadfence_system(); } } while (0)
+#else
+#define OSP_DESC_CHECK(t_, d_)
+#define OSP_CRUMB(ph_, a_, b_, c_)
+#endif
+
 // Phase timing for tools/bench_merge.hip (-DOSP_MERGE_PROF): thread 0 of every workgroup adds the cycles between
 // marks to osp_merge_prof[phase].  Compiled out of the library.
 #ifdef OSP_MERGE_PROF
@@ -602,19 +624,32 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
         if (t0 < ntiles) s_dnext = desc[t0];
     }
     __syncthreads();
+    // A workgroup that starts late -- the CUs were still busy with the previous kernel, or with another process -- can
+    // find every tile already taken by the workgroups that started on time.  Its descriptor slot was never filled:
+    // leave before anything reads it.  (Round 1's intermittent "memory access fault": the garbage level index of
+    // that slot indexed the kernel-argument arrays.)
+#ifndef OSP_TEST_NO_LATE_GUARD  // (defined only to show that tests/test_gpu_shared_device.py catches the old behaviour)
+    if (s_tnext >= ntiles) return;
+#endif
     const uint64_t out_base = (ABL & 32) ? 0ull : *out_base_p;
     const uint32_t colmask = colbits < 32 ? ((1u << colbits) - 1u) : 0xffffffffu;
     // the first tile's data is requested here; inside the loop the NEXT tile's data is requested while the
     // current tile's output is being written
     uint32_t t = s_tnext;
     TileDesc d = s_dnext;
+    OSP_CRUMB(5, ntiles, d.lvl, d.nr);
     uint64_t ro = 0;
     PartWords<T> lrec[LPT];  // raw: unpacked at staging time, so the loads stay in flight together
     auto request = [&](const TileDesc &dd, bool ok) {
         bool fetch = ok && dd.n <= (uint32_t)kTileCap;
         ro = 0;
-        const Part<T> *__restrict__ stage = lvl.stage[dd.lvl];
-        if (fetch && tid <= dd.nr) ro = lvl.row_off[dd.lvl][dd.ra + tid];
+#ifndef OSP_TEST_NO_LATE_GUARD
+        const uint32_t lv_i = dd.lvl & 1u;  // two levels; never index the argument arrays with anything else
+#else
+        const uint32_t lv_i = dd.lvl;
+#endif
+        const Part<T> *__restrict__ stage = lvl.stage[lv_i];
+        if (fetch && tid <= dd.nr) ro = lvl.row_off[lv_i][dd.ra + tid];
         if (ROWWISE && dd.lvl == 0) fetch = false;  // nothing was staged for these rows
 #pragma unroll
         for (int q = 0; q < LPT; q++) {
@@ -629,6 +664,8 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
     __syncthreads();  // everybody holds t / d before the slots are refilled
     OSP_PROF_DECL
     while (t < ntiles) {
+        OSP_DESC_CHECK(t, d);
+        OSP_CRUMB(1, ntiles, d.lvl, d.nr);
         const uint64_t ra = d.ra, s = d.s, base = lvl.base[d.lvl];
         const uint32_t nr = d.nr, n = d.n;
         int64_t *__restrict__ c_rowptr = lvl.c_rowptr[d.lvl];
@@ -885,6 +922,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
         // the values: read again (the tile went through L2 a few microseconds ago) rather than held in 18 registers
         // through the sort -- that is what lets five workgroups per CU run without spilling.  The barriers inside the
         // scan below order the LDS writes before the run sums.
+        OSP_CRUMB(2, npass, cur, nbits);
         if (!rw_tile) {
             const Part<T> *__restrict__ stg = lvl.stage[d.lvl];
             T vq[LPT];
@@ -969,6 +1007,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
         OSP_PROF_MARK(9);
         const uint32_t tn = s_tnext;
         const TileDesc dn = s_dnext;
+        OSP_CRUMB(3, total, tn, dn.s);
         // the next tile's HBM reads go out ahead of this tile's writes
         request(dn, tn < ntiles);
         if constexpr (INPLACE) {
@@ -983,11 +1022,13 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
             if (tid < nr) c_rowptr[ra + tid] = (int64_t)(obase + sm.rank[sm.rowo[tid]]);
             if (t + 1 == ntiles && tid == 0) *out_end_p = obase + total;
         }
+        OSP_CRUMB(4, total, tn, 0);
         t = tn;
         d = dn;
         __syncthreads();  // LDS is reused by the next tile
         OSP_PROF_MARK(10);
     }
+    OSP_CRUMB(7, ntiles, 0, 0);
     OSP_PROF_FLUSH;
 }
 

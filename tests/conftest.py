@@ -75,9 +75,8 @@ def ctx(request, _ctx_shared):
     """Every test that multiplies runs once per formulation (osp_config_t.algorithm): outer product with staging, and the
     row-wise variant that forms short rows inside the merge kernel.  Both must equal the oracle bit for bit.
 
-    ONE library context (device 0: stream + buffer pool) for the whole session.  A context per test module meant
-    freeing every pooled device buffer and allocating the same addresses again a moment later; the intermittent GPU
-    memory faults of round 1 clustered right after such a hand-over, and a process normally keeps one context anyway."""
+    ONE library context (device 0: stream + buffer pool) for the whole session: a process normally keeps one, and a
+    context per test module only meant freeing every pooled device buffer and allocating it again a moment later."""
     _ctx_shared.algorithm = request.param
     yield _ctx_shared
     _ctx_shared.algorithm = "outer"
