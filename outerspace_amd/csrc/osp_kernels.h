@@ -59,6 +59,34 @@ __device__ __forceinline__ PartWords<T> load_part_words(const Part<T> *p) { retu
 template <class T>
 __device__ __forceinline__ void store_part_words(Part<T> *p, const PartWords<T> &r) { *reinterpret_cast<PartWords<T> *>(p) = r; }
 
+// Streaming store of one record (written once, read much later by another kernel): non-temporal, so that the staging
+// buffer does not push the operands out of L2.  OSP_NT_STAGE=0 compiles the plain store (A/B measurements: multiply
+// 58 -> 48 ms on the default workload together with the non-temporal stores of the merge output).  The same hint on
+// the split kernels' scattered stores made them much slower (they need L2 to combine partial lines: 333 -> 394 ms);
+// on loads at their last use it made no difference.
+#ifndef OSP_NT_STAGE
+#define OSP_NT_STAGE 1
+#endif
+template <class T>
+__device__ __forceinline__ void stream_store_part(Part<T> *p, uint32_t col, T val) {
+#if OSP_NT_STAGE
+    if constexpr (sizeof(T) == 8) {
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+        const uint64_t b = (uint64_t)__double_as_longlong((double)val);
+        u32x3 v;
+        v.x = col; v.y = (uint32_t)b; v.z = (uint32_t)(b >> 32);
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x3 *>(p));
+    } else {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+        u32x2 v;
+        v.x = col; v.y = __float_as_uint((float)val);
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x2 *>(p));
+    }
+#else
+    *p = Part<T>{col, val};
+#endif
+}
+
 // error flag bits written by validate kernels
 constexpr uint32_t kFlagRange = 1u, kFlagUnsorted = 2u, kFlagDuplicate = 4u, kFlagPtr = 8u;
 
@@ -270,7 +298,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                         const T av = wave_bcast(av_l, q);
                         const uint64_t off = wave_bcast(off_l, q);
                         const bool ok = in && off != kChunkSkip && !(j == j0 && l < la) && !(j == j1 && l >= lb);
-                        if (ok) stage[off + l] = Part<T>{bc, av * bv};
+                        if (ok) stream_store_part(&stage[off + l], bc, av * bv);
                     }
                 }
             }
@@ -288,7 +316,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                 if (ok) {
                     const uint64_t e = as + j;
                     const uint64_t raw = chunk_off[e - (uint64_t)e0];
-                    if (raw != kChunkSkip) stage[raw - base + l] = Part<T>{bc, a_vals[e] * bv};
+                    if (raw != kChunkSkip) stream_store_part(&stage[raw - base + l], bc, a_vals[e] * bv);
                 }
             }
         }
@@ -657,7 +685,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
             // unconditional load from a clamped address (lanes past the end read the descriptor array and
             // ignore it): a branch here makes the compiler wait for every load inside its own block
             const Part<T> *src = (fetch && i < dd.n) ? &stage[dd.s + i] : reinterpret_cast<const Part<T> *>(desc);
-            lrec[q] = load_part_words(src);
+            lrec[q] = load_part_words(src);  // (a non-temporal load here costs the value reload its L2 hits: merge +6 %)
         }
     };
     request(d, t < ntiles);
@@ -1017,7 +1045,10 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
             if (tid == 0) const_cast<uint32_t *>(lvl.heavy_nnz[d.lvl])[ra] = total;
         } else {
             const uint64_t obase = out_base + sm.excl;
-            for (uint32_t o = tid; o < total; o += NT) { c_col[obase + o] = skey[o]; c_val[obase + o] = sval[o]; }
+            for (uint32_t o = tid; o < total; o += NT) {  // the result is not read again by this product: streaming stores
+                __builtin_nontemporal_store(skey[o], &c_col[obase + o]);
+                __builtin_nontemporal_store(sval[o], &c_val[obase + o]);
+            }
             // rows keep their index span through the sort (row is the major key)
             if (tid < nr) c_rowptr[ra + tid] = (int64_t)(obase + sm.rank[sm.rowo[tid]]);
             if (t + 1 == ntiles && tid == 0) *out_end_p = obase + total;
