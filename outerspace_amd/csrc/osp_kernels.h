@@ -28,7 +28,10 @@ template <> struct TileCap<double> { static constexpr int value = 1536; };
 constexpr int kMergeThreads = 256;
 constexpr int kTileMaxRows = kMergeThreads - 1;  // rows per tile: 8 row bits in the sort key, one row offset per thread
 constexpr int kMulThreads = 256;
-constexpr int kMulPerWave = 2048;  // partial products per wave slice
+#ifndef OSP_MUL_PER_WAVE
+#define OSP_MUL_PER_WAVE 2048
+#endif
+constexpr int kMulPerWave = OSP_MUL_PER_WAVE;  // partial products per wave slice
 constexpr int kMulPerBlock = kMulPerWave * (kMulThreads / kWave);
 
 // One staged partial product: 4-byte column + value, packed (12 B for f64, 8 B for f32).  Array of

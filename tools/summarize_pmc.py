@@ -34,7 +34,7 @@ def load(path):
             if s is None:
                 continue
             tot[s] += float(r["Counter_Value"]) * 1024.0
-            calls[s] += 1
+            calls[s] += int(r.get("Calls") or 1)  # (tools/profile_round.sh stores per-kernel sums with a call count)
     return tot, calls
 
 
