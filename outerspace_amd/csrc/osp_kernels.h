@@ -33,6 +33,10 @@ constexpr int kMulThreads = 256;
 #endif
 constexpr int kMulPerWave = OSP_MUL_PER_WAVE;  // partial products per wave slice
 constexpr int kMulPerBlock = kMulPerWave * (kMulThreads / kWave);
+#ifndef OSP_MUL_BATCH_MAX
+#define OSP_MUL_BATCH_MAX 4096
+#endif
+constexpr int kMulBatchMax = OSP_MUL_BATCH_MAX;  // 64 consecutive columns with at most this many products are multiplied as one batch
 
 // One staged partial product: 4-byte column + value, packed (12 B for f64, 8 B for f32).  Array of
 // records rather than two arrays: a chunk is then ONE contiguous byte range, which halves the number
@@ -265,6 +269,47 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
             kk++;
         }
         const uint64_t p0 = prod_off[kk], p1 = prod_off[kk + 1];
+        {
+            // Many small columns in a row (power-law graphs: most columns hold a handful of products): walking them one
+            // by one is a chain of dependent loads per column.  When the next 64 columns together hold at most
+            // kMulBatchMax products, lane q takes column kk+q's descriptors in ONE round of loads and the lanes walk the
+            // batch's products, each finding its column by bisecting the 64 start offsets with ds_bpermute.
+            const uint64_t kend = min(kk + (uint64_t)kWave, nk);
+            const uint64_t pend = prod_off[kend];
+            if (kend > kk + 1 && pend - p0 <= (uint64_t)kMulBatchMax) {
+                const uint64_t kq = kk + lane;
+                const bool cv = kq < kend;
+                const uint32_t rel0 = cv ? (uint32_t)(prod_off[kq] - p0) : (uint32_t)(pend - p0);  // lanes past the end: behind all
+                const uint64_t bsq = cv ? (uint64_t)b_rowptr[k0 + kq] : 0ull;
+                const uint32_t nbq = cv ? (uint32_t)((uint64_t)b_rowptr[k0 + kq + 1] - bsq) : 1u;
+                const uint64_t asq = cv ? (uint64_t)a_start[kq] : 0ull;
+                const uint32_t lo_p = (uint32_t)(cur - p0), hi_p = (uint32_t)(min(we, pend) - p0);
+                for (uint32_t x0 = lo_p; x0 < hi_p; x0 += kWave) {
+                    const uint32_t x = x0 + lane;
+                    uint32_t lo = 0, hi = kWave;  // last lane whose column starts at or before x (empty columns never win)
+#pragma unroll
+                    for (int step = 0; step < 6; step++) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if ((uint32_t)__shfl((int)rel0, (int)mid) <= x) lo = mid; else hi = mid;
+                    }
+                    const uint32_t r = x - (uint32_t)__shfl((int)rel0, (int)lo);
+                    const uint32_t nbx = (uint32_t)__shfl((int)nbq, (int)lo);
+                    const uint64_t bsx = (uint64_t)__shfl((long long)bsq, (int)lo);
+                    const uint64_t asx = (uint64_t)__shfl((long long)asq, (int)lo);
+                    if (x < hi_p) {
+                        const uint32_t j = r / nbx, l = r - j * nbx;
+                        const uint64_t e = asx + j;
+                        const uint64_t raw = chunk_off[e - (uint64_t)e0];
+                        const uint32_t bc = b_colidx[bsx + l];
+                        const T pv = a_vals[e] * b_vals[bsx + l];
+                        if (raw != kChunkSkip) stream_store_part(&stage[raw - base + l], bc, pv);
+                    }
+                }
+                cur = p0 + hi_p;
+                kk = kend - 1;
+                continue;
+            }
+        }
         const uint64_t k = k0 + kk;
         const uint64_t bs = (uint64_t)b_rowptr[k];
         const uint32_t nb = (uint32_t)((uint64_t)b_rowptr[k + 1] - bs);
