@@ -16,7 +16,13 @@
 namespace osp {
 
 constexpr int kSplitThreads = 256;
-constexpr int kSplitStretch = 4096;   // entries of one long row handled by one workgroup
+constexpr int kSplitStretch = 4096;   // entries a workgroup holds in registers at a time (one round)
+#ifndef OSP_SPLIT_JOB_ROUNDS
+#define OSP_SPLIT_JOB_ROUNDS 8
+#endif
+constexpr int kSplitJob = OSP_SPLIT_JOB_ROUNDS * kSplitStretch;  // entries of one long row handled by one workgroup of the stretch split:
+                                              // eight rounds share ONE histogram column (a 4096-cell column per 4096
+                                              // entries was a third of the split's traffic on Graph500 inputs)
 constexpr int kSplitMaxBits = 12;     // at most 4096 segments per row
 constexpr int kSplitTarget = 256;     // aim for segments of about this many entries
 constexpr int kSplitRowBits = 8;      // rows of at most 2^8 segments (<= 64K entries) are split by ONE workgroup
@@ -33,7 +39,7 @@ __global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const
     while (b < kSplitMaxBits && (1ull << b) < want) b++;
     b = min(b, colbits);
     const bool big = U > row_max || b > kSplitRowBits;
-    const uint32_t ns = big ? (uint32_t)((U + kSplitStretch - 1) / kSplitStretch) : 0u;  // 0 stretches = one-workgroup row
+    const uint32_t ns = big ? (uint32_t)((U + kSplitJob - 1) / kSplitJob) : 0u;  // 0 stretches = one-workgroup row
     hbits[h] = (uint8_t)b;
     nstretch[h] = ns;
     nseg[h] = 1u << b;
@@ -59,8 +65,8 @@ __device__ __forceinline__ SplitJob split_job(const uint32_t *rows, uint32_t nhe
     j.b = hbits[j.h];
     j.nst = nstretch[j.h];
     const uint64_t s = row_off[rows[j.h]] - base, e = row_off[rows[j.h] + 1] - base;
-    j.beg = s + (uint64_t)j.st * kSplitStretch;
-    j.end = min(j.beg + (uint64_t)kSplitStretch, e);
+    j.beg = s + (uint64_t)j.st * kSplitJob;
+    j.end = min(j.beg + (uint64_t)kSplitJob, e);
     j.hbase = hbase[j.h];
     return j;
 }
@@ -118,44 +124,61 @@ __global__ __launch_bounds__(kSplitThreads) void split_scatter_kernel(
     }
     __syncthreads();
     const int sh = colbits - (int)j.b;
-    // each wave owns a contiguous quarter of the stretch: earlier waves = earlier entries (stable)
-    const uint64_t wbeg = j.beg + (uint64_t)w * (kSplitStretch / NW);
-    uint32_t rk[ITERS];
-    PartWords<T> rec[ITERS];  // raw records: all loads in flight together
+    // the job's entries in rounds of kSplitStretch; boff[d] runs along (it always points behind what the earlier rounds
+    // put into segment d)
+    for (uint64_t sb = j.beg; sb < j.end; sb += kSplitStretch) {
+        const uint64_t se = min(sb + (uint64_t)kSplitStretch, j.end);
+        // each wave owns a contiguous quarter of the round: earlier waves = earlier entries (stable)
+        const uint64_t wbeg = sb + (uint64_t)w * (kSplitStretch / NW);
+        uint32_t rk[ITERS];
+        PartWords<T> rec[ITERS];  // raw records: all loads in flight together
 #pragma unroll
-    for (int it = 0; it < ITERS; it++) {
-        const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
-        rec[it] = load_part_words(&stage[i < j.end ? i : j.beg]);  // branch-free: lanes past the end re-read the first record
-    }
-#pragma unroll
-    for (int it = 0; it < ITERS; it++) {
-        const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
-        const bool valid = i < j.end;
-        const unsigned d = rec[it].col() >> sh;
-        unsigned r, c;
-        wave_match_bits(d, (int)j.b, valid, r, c);
-        if (valid) {
-            const uint32_t cur = cnt[w][d];
-            rk[it] = cur + r;
-            if (r == 0) cnt[w][d] = (uint16_t)(cur + c);
+        for (int it = 0; it < ITERS; it++) {
+            const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
+            rec[it] = load_part_words(&stage[i < se ? i : sb]);  // branch-free: lanes past the end re-read the first record
         }
-    }
-    __syncthreads();
-    // per segment: exclusive offsets of the waves, on top of the stretch's base
-    for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) {
-        uint32_t run = 0;
 #pragma unroll
-        for (int ww = 0; ww < NW; ww++) { const uint32_t c = cnt[ww][d]; cnt[ww][d] = (uint16_t)run; run += c; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < ITERS; it++) {
-        const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
-        if (i < j.end) {
+        for (int it = 0; it < ITERS; it++) {
+            const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
+            const bool valid = i < se;
             const unsigned d = rec[it].col() >> sh;
-            const uint32_t dst = boff[d] + cnt[w][d] + rk[it];
-            store_part_words(&qstage[dst], rec[it]);
+            unsigned r, c;
+            wave_match_bits(d, (int)j.b, valid, r, c);
+            rk[it] = 0;
+            if (valid) {
+                const uint32_t cur = cnt[w][d];
+                rk[it] = cur + r;
+                if (r == 0) cnt[w][d] = (uint16_t)(cur + c);
+            }
         }
+        __syncthreads();
+        // per segment: the waves' exclusive offsets, stored RELATIVE TO THE END of the round's entries of the segment
+        // (a small negative number in 16 bits), and boff moved to that end -- no extra counter row for the totals
+        for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) {
+            uint32_t total = 0;
+#pragma unroll
+            for (int ww = 0; ww < NW; ww++) total += cnt[ww][d];
+            uint32_t run = 0;
+#pragma unroll
+            for (int ww = 0; ww < NW; ww++) { const uint32_t c = cnt[ww][d]; cnt[ww][d] = (uint16_t)(run - total); run += c; }
+            boff[d] += total;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
+            if (i < se) {
+                const unsigned d = rec[it].col() >> sh;
+                const uint32_t dst = boff[d] + (uint32_t)(int32_t)(int16_t)cnt[w][d] + rk[it];
+                store_part_words(&qstage[dst], rec[it]);
+            }
+        }
+        __syncthreads();  // the scatter has read the counters
+        for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) {
+#pragma unroll
+            for (int ww = 0; ww < NW; ww++) cnt[ww][d] = 0;
+        }
+        __syncthreads();
     }
 }
 
