@@ -444,6 +444,9 @@ constexpr uint64_t kStatusAgg = 1ull << 62, kStatusPrefix = 2ull << 62, kStatusM
 #ifndef OSP_DIGIT_BITS
 #define OSP_DIGIT_BITS 10
 #endif
+#ifndef OSP_RANK_ATOMIC
+#define OSP_RANK_ATOMIC 1
+#endif
 constexpr int kDigitBits = OSP_DIGIT_BITS;    // widest radix of one LDS sort pass: 20 key bits sort in two passes
 constexpr int kDigits = 1 << kDigitBits;      // 1024 buckets
 
@@ -954,9 +957,31 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                     }
                 }
             };
+#if OSP_RANK_ATOMIC
+            // Rank by LDS atomic: one ds_add_rtn on the wave's packed 16-bit counter returns "entries of this digit so far",
+            // and lanes that hit the same counter in one instruction get their old values in ascending lane order -- which
+            // is exactly the stable rank.  (The order is not documented; tools/test_lds_atomic_order checked 1.8e10 ranks on
+            // gfx950 against the ballot match below, and every parity test compares values bit for bit, which an unstable
+            // rank would break.)
+            {
+                uint32_t(*cnt32)[kDigits / 2] = reinterpret_cast<uint32_t(*)[kDigits / 2]>(sm.cnt);
+#pragma unroll
+                for (int it = 0; it < ITERS; it++) {
+                    const uint32_t i = wbeg + it * kWave + lane;
+                    const bool valid = i < wend;
+                    kreg[it] = valid ? ksrc[i] : 0u;
+                    const unsigned dg = (kreg[it] >> shift) & dmask;
+                    const unsigned half = 16u * (dg & 1u);
+                    rreg[it] = 0;
+                    if (valid) rreg[it] = (atomicAdd(&cnt32[w][dg >> 1], 1u << half) >> half) & 0xffffu;
+                }
+                (void)rank_span;
+            }
+#else
             // the widest digits only when they save a pass (20 key bits in two passes); else one ballot less
             if (pbits > kDigitBits - 1) rank_span(std::integral_constant<int, kDigitBits>{});
             else rank_span(std::integral_constant<int, kDigitBits - 1>{});
+#endif
             __syncthreads();
             OSP_PROF_MARK(3);
             // (b) exclusive scan over (digit major, wave minor); a thread owns dpt consecutive digits

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kSplitThreads) void split_scatter_kernel(
     const uint32_t *goffs, const uint64_t *hoff, Part<T> *qstage) {
     constexpr int NW = kSplitThreads / kWave;
     constexpr int ITERS = kSplitStretch / kSplitThreads;  // 16 wave iterations per wave span
-    __shared__ uint16_t cnt[NW][1 << kSplitMaxBits];
+    __shared__ alignas(8) uint16_t cnt[NW][1 << kSplitMaxBits];  // (pairs of counters are also addressed as 32-bit words)
     __shared__ uint32_t boff[1 << kSplitMaxBits];
     const SplitJob j = split_job(rows, nheavy, blkbase, hbase, hbits, nstretch, row_off, base);
     const uint32_t nseg = 1u << j.b;
@@ -142,14 +142,20 @@ __global__ __launch_bounds__(kSplitThreads) void split_scatter_kernel(
             const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
             const bool valid = i < se;
             const unsigned d = rec[it].col() >> sh;
+            rk[it] = 0;
+#if OSP_RANK_ATOMIC
+            // stable rank by LDS atomic on the wave's packed 16-bit counter (see merge_tiles_kernel)
+            const unsigned half = 16u * (d & 1u);
+            if (valid) rk[it] = (atomicAdd(&reinterpret_cast<uint32_t *>(cnt[w])[d >> 1], 1u << half) >> half) & 0xffffu;
+#else
             unsigned r, c;
             wave_match_bits(d, (int)j.b, valid, r, c);
-            rk[it] = 0;
             if (valid) {
                 const uint32_t cur = cnt[w][d];
                 rk[it] = cur + r;
                 if (r == 0) cnt[w][d] = (uint16_t)(cur + c);
             }
+#endif
         }
         __syncthreads();
         // per segment: the waves' exclusive offsets, stored RELATIVE TO THE END of the round's entries of the segment
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
     constexpr int ITERS = kSplitStretch / kSplitThreads;
     constexpr int NSEG = 1 << kSplitRowBits;
     static_assert(NSEG <= kSplitThreads, "one thread per segment in the scan");
-    __shared__ uint16_t cnt[NW + 1][NSEG];
+    __shared__ alignas(8) uint16_t cnt[NW + 1][NSEG];
     __shared__ uint32_t segoff[NSEG];  // histogram, then running offset of every segment
     __shared__ uint32_t scratch[NW + 1];
     const uint32_t h = blockIdx.x;
@@ -248,14 +254,19 @@ __global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
             const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
             const bool valid = i < se;
             const unsigned d = rec[it].col() >> sh;
+            rk[it] = 0;
+#if OSP_RANK_ATOMIC
+            const unsigned half = 16u * (d & 1u);
+            if (valid) rk[it] = (atomicAdd(&reinterpret_cast<uint32_t *>(cnt[w])[d >> 1], 1u << half) >> half) & 0xffffu;
+#else
             unsigned r, c;
             wave_match_bits(d, (int)b, valid, r, c);
-            rk[it] = 0;
             if (valid) {
                 const uint32_t cur = cnt[w][d];
                 rk[it] = cur + r;
                 if (r == 0) cnt[w][d] = (uint16_t)(cur + c);
             }
+#endif
         }
         __syncthreads();
         // per segment: exclusive offsets of the waves inside this stretch; cnt[NW] keeps the stretch's total
