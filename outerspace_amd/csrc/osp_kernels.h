@@ -444,9 +444,6 @@ constexpr uint64_t kStatusAgg = 1ull << 62, kStatusPrefix = 2ull << 62, kStatusM
 #ifndef OSP_DIGIT_BITS
 #define OSP_DIGIT_BITS 10
 #endif
-#ifndef OSP_RANK_ATOMIC
-#define OSP_RANK_ATOMIC 1
-#endif
 constexpr int kDigitBits = OSP_DIGIT_BITS;    // widest radix of one LDS sort pass: 20 key bits sort in two passes
 constexpr int kDigits = 1 << kDigitBits;      // 1024 buckets
 

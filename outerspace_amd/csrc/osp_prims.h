@@ -8,6 +8,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Stable radix ranks by LDS atomic (1) or by ballot matching (0).  One ds_add_rtn instruction hands its old values to
+// the lanes that hit the same counter in ascending lane order -- undocumented, so tools/test_lds_atomic_order checks it
+// (1.8e10 ranks on gfx950, none out of order) and every parity test compares values bit for bit.
+#ifndef OSP_RANK_ATOMIC
+#define OSP_RANK_ATOMIC 1
+#endif
+
 namespace osp {
 
 constexpr int kWave = 64;
@@ -214,9 +221,14 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(
             val = vals_in[i];
         }
         const unsigned d = (unsigned)(key >> shift) & 255u;
+#if OSP_RANK_ATOMIC
+        unsigned rank = 0;  // stable rank by LDS atomic: old values come back in lane order (see merge_tiles_kernel)
+        if (valid) rank = atomicAdd(&cnt[w][d], 1u);
+#else
         const uint64_t peers = wave_match8(d, valid);
         const unsigned rank = __popcll(peers & lanemask_lt());
         if (valid && rank == 0) cnt[w][d] = (uint32_t)__popcll(peers);
+#endif
         __syncthreads();
         if (valid) {
             uint32_t off = base[d] + rank;

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
     constexpr int ITERS = SPAN / kWave;     // 16
     __shared__ uint32_t skey[kRsTile];
     __shared__ uint32_t sval[kRsTile];
-    __shared__ uint16_t cnt[NW][kRadix];
+    __shared__ alignas(8) uint16_t cnt[NW][kRadix];
     __shared__ uint32_t lstart[kRadix];     // first LDS slot of each digit
     __shared__ uint32_t gbase[kRadix];      // first global slot of each digit for this workgroup
     __shared__ uint32_t scratch[NW + 1];
@@ -78,14 +78,20 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
         const uint64_t i = tile + (uint64_t)w * SPAN + (uint64_t)it * kWave + lane;
         const bool valid = i < n;
         const unsigned d = (kreg[it] >> shift) & 255u;
+        rreg[it] = 0;
+#if OSP_RANK_ATOMIC
+        // stable rank by LDS atomic on the wave's packed 16-bit counter (see merge_tiles_kernel)
+        const unsigned half = 16u * (d & 1u);
+        if (valid) rreg[it] = (atomicAdd(&reinterpret_cast<uint32_t *>(cnt[w])[d >> 1], 1u << half) >> half) & 0xffffu;
+#else
         const uint64_t peers = wave_match8(d, valid);
         const unsigned rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
-        rreg[it] = 0;
         if (valid) {
             const uint32_t c = cnt[w][d];
             rreg[it] = c + rk;
             if (rk == 0) cnt[w][d] = (uint16_t)(c + (uint32_t)__popcll(peers));
         }
+#endif
     }
     __syncthreads();
     {   // digit totals -> LDS start of every digit, and per-wave offsets inside the digit
