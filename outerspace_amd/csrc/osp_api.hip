@@ -1224,6 +1224,21 @@ static int context_create(int device, void *stream, bool own, osp_context_t *out
     c->cus = (uint32_t)prop.multiProcessorCount;
     if (own) { OSP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     else c->stream = (hipStream_t)stream;
+#if OSP_RANK_ATOMIC
+    try {
+        Scratch sc(c);
+        uint32_t *bad = sc.get<uint32_t>(1);
+        OSP_HIP(hipMemsetAsync(bad, 0, sizeof(uint32_t), c->stream));
+        rank_order_selftest_kernel<<<64, 256, 0, c->stream>>>(bad);
+        if (d2h(bad, c->stream) != 0)
+            throw Error(OSP_ERR_HIP, "LDS atomics do not return their old values in lane order on this device: build with -DOSP_RANK_ATOMIC=0");
+    } catch (...) {
+        c->trim();
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        throw;
+    }
+#endif
     *out = (osp_context_t)c;
     return OSP_OK;
     OSP_GUARD_END

@@ -498,6 +498,33 @@ __device__ __forceinline__ void wave_match_digit(unsigned digit, bool valid, uns
     count = __popc(plo) + __popc(phi);
 }
 
+// Self-test run once per context: does one LDS atomic-add instruction hand out its old values in ascending lane order
+// among the lanes that hit the same counter?  The stable ranks of every radix pass rely on it (OSP_RANK_ATOMIC); it holds
+// on gfx950 but is not documented, so a device where it does not must fail loudly rather than sum in another order.
+__global__ __launch_bounds__(256) void rank_order_selftest_kernel(uint32_t *bad) {
+    __shared__ uint32_t cnt[4][64];
+    const unsigned tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    uint32_t x = 0x9E3779B9u * (blockIdx.x * 256u + tid + 1u), nbad = 0;
+    for (int r = 0; r < 64; r++) {
+        cnt[w][lane] = 0;
+        for (int it = 0; it < 4; it++) {
+            x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+            const unsigned dg = (x >> 9) & ((r & 1) ? 3u : 127u);  // every other round: four counters for 64 lanes
+            const bool valid = ((x >> 27) & 7u) != 0;
+            unsigned rk, c;
+            wave_match_digit<7>(dg, valid, rk, c);
+            const unsigned half = 16u * (dg & 1u);
+            const uint32_t before = (cnt[w][dg >> 1] >> half) & 0xffffu;
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                const uint32_t got = (atomicAdd(&cnt[w][dg >> 1], 1u << half) >> half) & 0xffffu;
+                nbad += got != before + rk;
+            }
+        }
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
 // Exclusive prefix of tile `t` by decoupled look-back (called by wave 0 of the block).
 // One round trip fetches kLookWin windows of 64 predecessors.  (Measured: wide windows lose -- the
 // extra polling traffic costs more than the walk saves -- so kLookWin = 1; what matters is that tiles
