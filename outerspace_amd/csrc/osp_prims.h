@@ -144,6 +144,36 @@ __global__ __launch_bounds__(kScanThreads) void scan_tiles_kernel(F f, uint64_t 
 template <class TOut>
 __global__ void scan_empty_kernel(TOut *out) { out[0] = 0; }
 
+// Short inputs (the per-long-row and per-coarse-block arrays of a product: a few hundred to a few thousand entries): one
+// workgroup walks the tiles with a running carry -- one launch instead of three.  In-place use (out == the array f reads)
+// is fine: a tile's inputs are in registers before its outputs are written.
+constexpr uint64_t kScanSmallTiles = 16;
+template <class F, class TOut>
+__global__ __launch_bounds__(kScanThreads) void scan_small_kernel(F f, uint64_t n, TOut *out) {
+    __shared__ TOut scratch[kScanThreads / kWave + 1];
+    TOut carry = 0;
+    for (uint64_t base = 0; base < n; base += kScanTile) {
+        TOut v[kScanItems];
+        TOut s = 0;
+#pragma unroll
+        for (int i = 0; i < kScanItems; i++) {
+            const uint64_t idx = base + (uint64_t)threadIdx.x * kScanItems + i;
+            v[i] = idx < n ? (TOut)f(idx) : (TOut)0;
+            s += v[i];
+        }
+        TOut total;
+        TOut ex = block_excl_scan<TOut, kScanThreads>(s, scratch, &total) + carry;
+#pragma unroll
+        for (int i = 0; i < kScanItems; i++) {
+            const uint64_t idx = base + (uint64_t)threadIdx.x * kScanItems + i;
+            if (idx < n) out[idx] = ex;
+            ex += v[i];
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+}
+
 // `tile_scratch` needs ceil(n / kScanTile) + 1 entries of TOut.
 template <class F, class TOut>
 inline void device_exclusive_scan(F f, uint64_t n, TOut *out, TOut *tile_scratch,
@@ -153,6 +183,10 @@ inline void device_exclusive_scan(F f, uint64_t n, TOut *out, TOut *tile_scratch
         return;
     }
     const uint64_t ntiles = (n + kScanTile - 1) / kScanTile;
+    if (ntiles <= kScanSmallTiles) {
+        scan_small_kernel<F, TOut><<<1, kScanThreads, 0, stream>>>(f, n, out);
+        return;
+    }
     scan_tile_sums_kernel<F, TOut><<<(unsigned)ntiles, kScanThreads, 0, stream>>>(f, n, tile_scratch);
     scan_tile_offsets_kernel<TOut><<<1, kScanThreads, 0, stream>>>(tile_scratch, ntiles);
     scan_tiles_kernel<F, TOut><<<(unsigned)ntiles, kScanThreads, 0, stream>>>(f, n, tile_scratch, out);
