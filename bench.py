@@ -315,6 +315,10 @@ def main():
             "panels": info["panels"], "long_rows_split": info["heavy_rows"], "long_row_partials": info["heavy_partials"],
             "segments_global_sorted": info["sorted_segments"], "segment_partials_global_sorted": info["sorted_partials"],
             "roofline": roof,
+            # per-step device times (ms): how much the numbers above move from one product to the next
+            "steps_ms": {"total": [round(i["ms_total"], 2) for i in infos],
+                         "multiply_kernel": [round(i["ms_multiply_kernel"], 2) for i in infos],
+                         "merge_kernel": [round(i["ms_merge_kernel"], 2) for i in infos]},
             "result_check": {"sum_C": chk["val_sum_global"], "expected_(1^T A)(B 1)": want_sum, "rel_err": rel},
         }
         if use_dist:
