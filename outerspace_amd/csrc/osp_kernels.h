@@ -1057,22 +1057,18 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
         // through the sort -- that is what lets five workgroups per CU run without spilling.  The barriers inside the
         // scan below order the LDS writes before the run sums.
         OSP_CRUMB(2, npass, cur, nbits);
+        T vq[LPT];
         if (!rw_tile) {
             const Part<T> *__restrict__ stg = lvl.stage[d.lvl];
-            T vq[LPT];
 #pragma unroll
             for (int q = 0; q < LPT; q++) {
                 const uint32_t i = tid + q * NT;
                 vq[q] = load_part_words(i < n ? &stg[s + i] : reinterpret_cast<const Part<T> *>(desc)).val();  // clamped, branch-free
             }
-#pragma unroll
-            for (int q = 0; q < LPT; q++) {
-                const uint32_t i = tid + q * NT;
-                if (i < n) sval[i] = vq[q];
-            }
         }
         if (npass == 0) __syncthreads();
-        // head flags + exclusive scan (blocked: thread owns IPT consecutive sorted entries)
+        // head flags + exclusive scan (blocked: thread owns IPT consecutive sorted entries) -- while the values are on
+        // their way
         const uint32_t ib = tid * IPT;
         uint32_t heads = 0, hmask = 0;
 #pragma unroll
@@ -1082,6 +1078,13 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                 const bool h = (i == 0) || (skey[i] != skey[i - 1]);
                 hmask |= (h ? 1u : 0u) << q;
                 heads += h;
+            }
+        }
+        if (!rw_tile) {
+#pragma unroll
+            for (int q = 0; q < LPT; q++) {
+                const uint32_t i = tid + q * NT;
+                if (i < n) sval[i] = vq[q];
             }
         }
         uint32_t total;
