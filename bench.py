@@ -293,6 +293,13 @@ def main():
             per = ms / nl
             kernels[name] = {"algorithmic_bytes_per_launch": nbytes, "ms_per_launch": per, "launches_per_step": nl,
                              "GBps": (nbytes / (per * 1e-3) / 1e9) if per > 0 else 0.0}
+        if info.get("split_launches"):
+            # the one-workgroup split of long rows: two reads and one write of every record it moves
+            nsp = info["split_launches"]
+            per = mean("ms_split_kernel") / nsp
+            nbytes = 3.0 * E * info["split_partials"] / nsp
+            kernels["split_row_kernel"] = {"algorithmic_bytes_per_launch": nbytes, "ms_per_launch": per, "launches_per_step": nsp,
+                                           "GBps": (nbytes / (per * 1e-3) / 1e9) if per > 0 else 0.0}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
@@ -318,7 +325,8 @@ def main():
             # per-step device times (ms): how much the numbers above move from one product to the next
             "steps_ms": {"total": [round(i["ms_total"], 2) for i in infos],
                          "multiply_kernel": [round(i["ms_multiply_kernel"], 2) for i in infos],
-                         "merge_kernel": [round(i["ms_merge_kernel"], 2) for i in infos]},
+                         "merge_kernel": [round(i["ms_merge_kernel"], 2) for i in infos],
+                         "split_row_kernel": [round(i["ms_split_kernel"], 2) for i in infos]},
             "result_check": {"sum_C": chk["val_sum_global"], "expected_(1^T A)(B 1)": want_sum, "rel_err": rel},
         }
         if use_dist:

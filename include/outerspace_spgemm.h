@@ -99,6 +99,10 @@ typedef struct osp_result_info {
     float ms_ingest;            /* osp_spgemm_coo / osp_spgemm_mtx: COO -> CSC/CSR on the device (included in ms_total) */
     uint32_t multiply_launches, merge_launches; /* number of those launches */
     int dtype;
+    float ms_split_kernel;      /* split_row_kernel launches alone (long rows of up to 64 K partial products) */
+    uint32_t split_launches;
+    uint64_t split_partials;    /* partial products those launches moved (lower bound: heavy_partials minus the
+                                   capacity of the stretch-split jobs) */
 } osp_result_info_t;
 
 /* ---- context ------------------------------------------------------------------------- */

@@ -248,7 +248,7 @@ struct Result {
 
 struct PhaseTimer {
     hipStream_t s;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[6];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[7];
     explicit PhaseTimer(hipStream_t st) : s(st) {}
     ~PhaseTimer() {
         for (auto &v : ev) for (auto &p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -267,7 +267,7 @@ struct PhaseTimer {
         return t;
     }
 };
-enum { PH_SYM = 0, PH_MUL = 1, PH_MERGE = 2, PH_COMPACT = 3, PH_MUL_K = 4, PH_MERGE_K = 5 };
+enum { PH_SYM = 0, PH_MUL = 1, PH_MERGE = 2, PH_COMPACT = 3, PH_MUL_K = 4, PH_MERGE_K = 5, PH_SPLIT_K = 6 };
 
 // debugging aid: OSP_SYNC=1 waits for the stream at the marked points of a product and names them on stderr, so
 // that an asynchronous GPU fault is pinned to the step that caused it (the last name printed COMPLETED)
@@ -490,8 +490,12 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         uint64_t *vrow_off = sc.get<uint64_t>(nvirt + 1);
         uint8_t *vfirst = sc.get<uint8_t>(nvirt + 1);
         // rows up to kSplitRowMax: one workgroup each (histogram, scan and scatter in one kernel)
+        tm.begin(PH_SPLIT_K);
         split_row_kernel<T><<<nlong, kSplitThreads, 0, s>>>(p0.long_rows, nlong, hbits, nstretch, vbase, hoff, io.row_off, base, colbits,
                                                             io.stage, qstage, vrow_off);
+        tm.end(PH_SPLIT_K);
+        res->info.split_launches++;
+        res->info.split_partials += nh - std::min<uint64_t>(nh, nblocks * (uint64_t)kSplitJob);
         dbg_sync(s, "split: one-workgroup rows");
         if (nblocks) {  // longer rows: one workgroup per 4096-entry stretch, offsets from a device-wide scan
             split_count_kernel<<<(unsigned)nblocks, kSplitThreads, 0, s>>>(p0.long_rows, nlong, blkbase, hbase, hbits, nstretch, io.row_off,
@@ -1029,6 +1033,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     res->info.ms_compact = tm.total(PH_COMPACT);
     res->info.ms_multiply_kernel = tm.total(PH_MUL_K);
     res->info.ms_merge_kernel = tm.total(PH_MERGE_K);
+    res->info.ms_split_kernel = tm.total(PH_SPLIT_K);
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
 }
@@ -1155,6 +1160,7 @@ static void merge_parts_impl(Context *ctx, Result *res, uint64_t M, uint64_t N, 
     res->info.ms_compact = tm.total(PH_COMPACT);
     res->info.ms_multiply_kernel = tm.total(PH_MUL_K);
     res->info.ms_merge_kernel = tm.total(PH_MERGE_K);
+    res->info.ms_split_kernel = tm.total(PH_SPLIT_K);
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
 }
