@@ -213,9 +213,18 @@ struct SymEpilogue {
 // w[t] = nnz(B[k,:]), bs[t] = b_rowptr[k] for the t-th non-zero of A's shard (CSC order, column k)
 __global__ void sym_chunk_len_kernel(const int64_t *a_colptr, const int64_t *b_rowptr, uint64_t k0, uint64_t k1, int64_t e0,
                                      uint64_t nnz, uint32_t *w, uint32_t *bs) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // the block's 256 consecutive entries lie in a short range of columns: two full searches per block (first and last
+    // entry), then every thread bisects that range only (~4 steps instead of ~22)
+    __shared__ uint64_t krange[2];
+    const uint64_t tb = (uint64_t)blockIdx.x * blockDim.x;
+    if (threadIdx.x < 2) {
+        const uint64_t tt = threadIdx.x == 0 ? tb : min(tb + blockDim.x, nnz) - 1;
+        krange[threadIdx.x] = upper_bound_dev(a_colptr, k0, k1 + 1, e0 + (int64_t)tt) - 1;
+    }
+    __syncthreads();
+    const uint64_t t = tb + threadIdx.x;
     if (t >= nnz) return;
-    const uint64_t k = upper_bound_dev(a_colptr, k0, k1 + 1, e0 + (int64_t)t) - 1;
+    const uint64_t k = upper_bound_dev(a_colptr, krange[0], krange[1] + 1, e0 + (int64_t)t) - 1;
     w[t] = (uint32_t)(b_rowptr[k + 1] - b_rowptr[k]);
     if (bs) bs[t] = (uint32_t)b_rowptr[k];
 }
