@@ -34,7 +34,7 @@ def skewed_coo(rng, nrow, ncol, nnz, alpha, dtype):
     return (key // ncol).astype(np.uint32), (key % ncol).astype(np.uint32), vals
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OSP_FUZZ_SEEDS", "24"))))  # OSP_FUZZ_SEEDS=200: a soak run
 def test_random_products_match_the_oracle(ctx, port, monkeypatch, seed):
     from outerspace_amd import spgemm as S
     rng = np.random.default_rng(1000 + seed)
