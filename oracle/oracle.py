@@ -199,6 +199,35 @@ class _Ref:
         return out
 
 
+    #: osp_ref_spgemm_variant: which of the reference's producers / mergers forms the product
+    VARIANTS = {
+        "cscMulcsr+deduplicateCOO": 0,            # SimSpGEMM.cpp:265-281 + :519-535 (the path the build replaces)
+        "csc2rawcompact+compactMulcsr": 1,        # :221-242 + :247-263, merged by deduplicateCOO
+        "csr2compact+compactMulcsr": 2,           # :154-219 + :247-263, merged by deduplicateCOO
+        "csr2compact+merge": 3,                   # :154-219 + merge/mergeHardware/multHardware/merge2way :306-517
+    }
+
+    def spgemm_variant(self, variant, M, K, a_colptr, a_rowidx, a_val, b_rowptr, b_colidx, b_val):
+        """The product through one of the reference's own alternative formulations (``VARIANTS``).
+        Returns (rc, dict(rows, cols, vals, nnzc, partials)); rc 6 = the reference's merge() would trip its
+        own assert for this input (see ref_driver.cpp), rc 233 = its dupcheck threw."""
+        pad = lambda x, t: np.ascontiguousarray(x, t) if len(x) else np.zeros(1, t)
+        nnzc, P = C.c_uint64(), C.c_uint64()
+        r, c, v = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)(), C.POINTER(self.cty)()
+        fn = self.lib.osp_ref_spgemm_variant
+        fn.argtypes = [C.c_int, C.c_uint64, C.c_uint64, _i64p, _u32p, _vp(self.dtype), _i64p, _u32p,
+                       _vp(self.dtype)] + [C.c_void_p] * 5
+        rc = fn(int(self.VARIANTS.get(variant, variant)), M, K, np.ascontiguousarray(a_colptr, np.int64),
+                pad(a_rowidx, np.uint32), pad(a_val, self.dtype), np.ascontiguousarray(b_rowptr, np.int64),
+                pad(b_colidx, np.uint32), pad(b_val, self.dtype), C.byref(nnzc), C.byref(P), C.byref(r), C.byref(c),
+                C.byref(v))
+        if rc:
+            return rc, None
+        out = dict(nnzc=nnzc.value, partials=P.value)
+        out["rows"], out["cols"], out["vals"] = self._take(nnzc.value, r, c, v)
+        return 0, out
+
+
 _port = None
 _refs = {}
 

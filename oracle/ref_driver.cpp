@@ -1,22 +1,28 @@
 // ref_driver.cpp -- TEST INFRASTRUCTURE ONLY.
 //
-// Compiles the REFERENCE's own translation unit simulator/SimSpGEMM.cpp, in place
-// under /root/reference (found through -I, see oracle/Makefile; never copied), and
-// exposes its live functions through a small C ABI so that
-//   * tests/golden/make_golden.py can generate golden vectors, and
+// Compiles the REFERENCE's own translation unit simulator/SimSpGEMM.cpp and exposes its
+// functions through a small C ABI so that
+//   * tests/golden/make_golden.py can generate golden vectors,
+//   * tests/test_oracle_golden.py can cross-check the reference's three producers and two mergers
+//     against each other and against the plain-C restatement, and
 //   * bench.py can time the reference algorithm as cpu_baseline.kind="reference".
-// Output goes to oracle/_ref/ only (git-ignored; it still travels to the GPU box).
+// Output goes to oracle/_ref/ only (git-ignored; the .so still travels to the GPU box).
 //
-// How the reference TU is taken in without touching it:
+// How the reference TU is taken in (recipe: oracle/Makefile):
+//   * The merge half of the path -- deduplicateCOO (:519-535), merge2way (:306-327), multHardware
+//     (:358-409), mergeHardware (:411-441), merge (:445-517) -- sits between `#if 0` (line 304) and
+//     `#endif` (line 812).  The Makefile writes the TU with that ONE line changed to `#if 1` into a
+//     mktemp directory OUTSIDE the repository (`sed '304s/^#if 0$/#if 1/'`, after checking that line
+//     304 is exactly `#if 0`), passes the directory with -I, and deletes it when the compiler returns.
+//     Nothing of the reference's text is copied into the tree; OSP_REF_TU names that temporary file.
+//   * The enabled block needs SimCache (`SimCache cache(8, 13, 3)`, :340): the reference's own
+//     simulator/SimCache.h is included in place (the TU's own include of it is commented out, :18).
 //   * `main` is renamed to an unused static function, so its one unresolvable call
-//     (simulateOuterSPACE, defined in SimOuterSPACE.cpp which needs the absent
-//     ramulator) is discarded with it -- no stand-in is written for anything.
-//   * the f64 build (-DOSP_REF_F64) compiles the same TU with `float` spelled
-//     `double`, which turns `typedef float value_t` (common.h:8) into double; the
-//     system headers the TU uses are included first so the macro cannot reach them.
-//   * deduplicateCOO (SimSpGEMM.cpp:519-535) sits inside `#if 0` and cannot be
-//     compiled in place; ref_merge() below performs its three statements with the
-//     reference's own COOElement::operator< (common.h:29-32) and std::sort.
+//     (simulateOuterSPACE, defined in SimOuterSPACE.cpp which needs the absent ramulator) is
+//     discarded with it -- no stand-in is written for anything.
+//   * the f64 build (-DOSP_REF_F64) compiles the same TU with `float` spelled `double`, which turns
+//     `typedef float value_t` (common.h:8) into double; the system headers the TU uses are included
+//     first so the macro cannot reach them.
 #include <cstdio>
 #include <cstdint>
 #include <cstdlib>
@@ -33,12 +39,20 @@
 #include <map>
 #include <cassert>
 #include <cmath>
+#include <list>
+#include <unordered_map>
+
+#ifndef OSP_REF_TU
+#error "build through oracle/Makefile: OSP_REF_TU names the reference TU with its merge block enabled"
+#endif
 
 #ifdef OSP_REF_F64
 #define float double
 #endif
+#include "simulator/common.h"
+#include "simulator/SimCache.h"
 #define main static __attribute__((unused)) osp_ref_unused_main
-#include "simulator/SimSpGEMM.cpp"
+#include OSP_REF_TU
 #undef main
 #ifdef OSP_REF_F64
 #undef float
@@ -48,22 +62,6 @@ namespace {
 
 double now() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-// deduplicateCOO, SimSpGEMM.cpp:519-535 (guarded for the empty input the original
-// would dereference).
-COOMatrix ref_merge(COOMatrix coo) {
-    COOMatrix result;
-    if (coo.empty()) return result;
-    std::sort(coo.begin(), coo.end());
-    result.push_back(coo.front());
-    for (size_t i = 1; i < coo.size(); i++) {
-        if (coo[i].row != coo[i - 1].row || coo[i].col != coo[i - 1].col)
-            result.push_back(coo[i]);
-        else
-            result.back().val += coo[i].val;
-    }
-    return result;
 }
 
 int export_coo(const COOMatrix &c, uint64_t *n, uint32_t **rows, uint32_t **cols, value_t **vals) {
@@ -78,6 +76,32 @@ int export_coo(const COOMatrix &c, uint64_t *n, uint32_t **rows, uint32_t **cols
         (*vals)[i] = c[i].val;
     }
     return 0;
+}
+
+COOMatrix concat(std::vector<COOMatrix> &parts, size_t *P) {
+    COOMatrix all;
+    size_t n = 0;
+    for (auto &p : parts) n += p.size();
+    all.reserve(n);
+    for (auto &p : parts) all.insert(all.end(), p.begin(), p.end());
+    std::vector<COOMatrix>().swap(parts);
+    if (P) *P = n;
+    return all;
+}
+
+// the reference's deduplicateCOO (:519-535) reads coo.front() of an empty input
+COOMatrix dedup(COOMatrix all) {
+    if (all.empty()) return COOMatrix();
+    return deduplicateCOO(std::move(all));
+}
+
+// slab [k0,k1) of compressed SoA operands -> the reference's CSRMatrix
+void load_slab(uint64_t k0, uint64_t k1, const int64_t *pos, const uint32_t *idx, const value_t *val, CSRMatrix &m) {
+    const size_t nk = k1 - k0;
+    m.pos.resize(nk + 1);
+    for (size_t k = 0; k <= nk; k++) m.pos[k] = (size_t)(pos[k0 + k] - pos[k0]);
+    m.data.resize(m.pos[nk]);
+    for (size_t i = 0; i < m.data.size(); i++) m.data[i] = CSRElement{idx[pos[k0] + i], val[pos[k0] + i]};
 }
 
 }  // namespace
@@ -120,7 +144,7 @@ int osp_ref_coo2csr(int transpose, uint64_t nseg, uint64_t nnz, const uint32_t *
 }
 
 // The numeric path of SURVEY.md section 3(b) on already-compressed operands, for
-// the k-slab [k0,k1):  cscMulcsr (:265-281) -> concat -> sort+sum (:519-535).
+// the k-slab [k0,k1):  cscMulcsr (:265-281) -> concat -> deduplicateCOO (:519-535).
 // Result is COO sorted by (row,col).  secs = {multiply+concat, merge} seconds.
 int osp_ref_spgemm_csx(uint64_t K, uint64_t k0, uint64_t k1, const int64_t *a_pos,
                        const uint32_t *a_idx, const value_t *a_val, const int64_t *b_pos,
@@ -129,30 +153,14 @@ int osp_ref_spgemm_csx(uint64_t K, uint64_t k0, uint64_t k1, const int64_t *a_po
                        double *secs) {
     if (k1 > K || k0 > k1) return 2;
     CSRMatrix csc, csr;
-    size_t nk = k1 - k0;
-    csc.pos.resize(nk + 1);
-    csr.pos.resize(nk + 1);
-    for (size_t k = 0; k <= nk; k++) {
-        csc.pos[k] = (size_t)(a_pos[k0 + k] - a_pos[k0]);
-        csr.pos[k] = (size_t)(b_pos[k0 + k] - b_pos[k0]);
-    }
-    csc.data.resize(csc.pos[nk]);
-    csr.data.resize(csr.pos[nk]);
-    for (size_t i = 0; i < csc.data.size(); i++)
-        csc.data[i] = CSRElement{a_idx[a_pos[k0] + i], a_val[a_pos[k0] + i]};
-    for (size_t i = 0; i < csr.data.size(); i++)
-        csr.data[i] = CSRElement{b_idx[b_pos[k0] + i], b_val[b_pos[k0] + i]};
-
+    load_slab(k0, k1, a_pos, a_idx, a_val, csc);
+    load_slab(k0, k1, b_pos, b_idx, b_val, csr);
     double t0 = now();
     std::vector<COOMatrix> parts = cscMulcsr(csc, csr);
-    COOMatrix all;
     size_t P = 0;
-    for (auto &p : parts) P += p.size();
-    all.reserve(P);
-    for (auto &p : parts) all.insert(all.end(), p.begin(), p.end());
-    std::vector<COOMatrix>().swap(parts);
+    COOMatrix all = concat(parts, &P);
     double t1 = now();
-    COOMatrix c = ref_merge(std::move(all));
+    COOMatrix c = dedup(std::move(all));
     double t2 = now();
     if (partials) *partials = P;
     if (secs) {
@@ -164,6 +172,57 @@ int osp_ref_spgemm_csx(uint64_t K, uint64_t k0, uint64_t k1, const int64_t *a_po
         return 0;
     }
     return export_coo(c, nnzc, rows, cols, vals);
+}
+
+// The same product through the reference's ALTERNATIVE producers and mergers (SURVEY.md 8a rows
+// "merge2way/mergeHardware/merge/multHardware" and "csr2compact/compactMulcsr/csc2rawcompact"):
+//   variant 0  deduplicateCOO(concat(cscMulcsr(csc, csr)))                        :265-281 + :519-535
+//   variant 1  deduplicateCOO(concat(compactMulcsr(csc2rawcompact(csc), csr)))    :221-242, :247-263
+//   variant 2  deduplicateCOO(concat(compactMulcsr(csr2compact(A_csr), csr)))     :154-219, :247-263
+//   variant 3  merge(csr2compact(A_csr), csr)   -- multHardware + the 6-layer merge2way tree      :306-517
+// A_csr = coo2csr<false>(A as COO, M), the reference's own conversion (:102-152).
+// Return codes: 0 ok; 2 bad argument; 233 = dupcheck threw (:49; compactMulcsr and mergeHardware call it);
+// 6 = the reference's merge() would fail its own assert(tmp.size() <= mergeK) (:483): when A's longest row has
+// more than MAX_MERGE_K = 64 non-zeros and that count is a multiple of 63, mergeK starts at 0 (:457).
+int osp_ref_spgemm_variant(int variant, uint64_t M, uint64_t K, const int64_t *a_pos, const uint32_t *a_idx,
+                           const value_t *a_val, const int64_t *b_pos, const uint32_t *b_idx,
+                           const value_t *b_val, uint64_t *nnzc, uint64_t *partials, uint32_t **rows,
+                           uint32_t **cols, value_t **vals) {
+    if (variant < 0 || variant > 3) return 2;
+    CSRMatrix csc, csr;
+    load_slab(0, K, a_pos, a_idx, a_val, csc);
+    load_slab(0, K, b_pos, b_idx, b_val, csr);
+    try {
+        COOMatrix c;
+        size_t P = 0;
+        if (variant == 0) {
+            std::vector<COOMatrix> parts = cscMulcsr(csc, csr);
+            c = dedup(concat(parts, &P));
+        } else if (variant == 1) {
+            std::vector<COOMatrix> parts = compactMulcsr(csc2rawcompact(csc), csr);
+            c = dedup(concat(parts, &P));
+        } else {
+            // A in row-major form through the reference's own conversion
+            const CompactCOOMatrix raw = csc2rawcompact(csc);
+            const CSRMatrix a_csr = coo2csr<false>(raw.data, (size_t)M);
+            const CompactCOOMatrix compact = csr2compact(a_csr);
+            for (size_t k = 0; k < K; k++) P += (csc.pos[k + 1] - csc.pos[k]) * (csr.pos[k + 1] - csr.pos[k]);
+            if (variant == 2) {
+                std::vector<COOMatrix> parts = compactMulcsr(compact, csr);
+                c = dedup(concat(parts, nullptr));
+            } else {
+                const size_t ways = compact.pos.empty() ? 0 : compact.pos.size() - 1;
+                if (ways > MAX_MERGE_K && ways % (MAX_MERGE_K - 1) == 0) return 6;
+                c = merge(compact, csr);
+                simRowOrder.clear();  // the reference's global access log (:344) only grows
+                simRowOrder.shrink_to_fit();
+            }
+        }
+        if (partials) *partials = P;
+        return export_coo(c, nnzc, rows, cols, vals);
+    } catch (int e) {
+        return e;
+    }
 }
 
 // The CLI data flow of main(), SimSpGEMM.cpp:819-891, from two .mtx paths:
@@ -193,9 +252,7 @@ int osp_ref_spgemm_mtx(const char *path_a, const char *path_b, int transpose_b, 
         for (size_t i = 0; i + 1 < csr.pos.size(); i++)
             mulflops += (csc.pos[i + 1] - csc.pos[i]) * (csr.pos[i + 1] - csr.pos[i]);
         std::vector<COOMatrix> parts = cscMulcsr(csc, csr);
-        COOMatrix all;
-        for (auto &p : parts) all.insert(all.end(), p.begin(), p.end());
-        COOMatrix c = ref_merge(std::move(all));
+        COOMatrix c = dedup(concat(parts, nullptr));
         *M = NRow[0];
         *N = NCol[1];
         *partials = mulflops;

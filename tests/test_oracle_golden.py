@@ -165,3 +165,72 @@ def test_kslab_decomposition(port):
     assert P == full["partials"] == port.mulflops(n, apos, bpos)
     ref = sp.csr_matrix((full["vals"], full["colidx"], full["rowptr"]), shape=(n, n))
     assert abs(acc - ref).max() < 1e-9
+
+
+# ---- the reference's alternative producers and mergers (merge2way / mergeHardware / merge / multHardware,
+# ---- csr2compact / compactMulcsr / csc2rawcompact), compiled from the reference's own text (oracle/Makefile) ----------
+def _variant_inputs(golden_dir, port, case, dt):
+    if case == "c1":
+        _, _, ar, ac, av = port.readcoo(os.path.join(golden_dir, "c1_A.mtx"))
+        _, _, br, bc, bv = port.readcoo(os.path.join(golden_dir, "c1_B.mtx"))
+        return 64, 64, 64, (ar, ac, av), (bc, br, bv)   # A * B^T, the CLI's product
+    if case == "rect":
+        g = load(golden_dir, "edges_expected.npz")
+        return 5, 7, 3, (g["rect_a_rows"], g["rect_a_cols"], g["rect_a_vals"]), (g["rect_b_rows"], g["rect_b_cols"], g["rect_b_vals"])
+    if case == "cancel":
+        g = load(golden_dir, "edges_expected.npz")
+        return 2, 2, 2, (g["cancel_a_rows"], g["cancel_a_cols"], g["cancel_a_vals"]), (g["cancel_b_rows"], g["cancel_b_cols"], g["cancel_b_vals"])
+    if case == "mlp":
+        _, _, ar, ac, av = port.readcoo(os.path.join(golden_dir, "mlp_act.mtx"))
+        _, _, br, bc, bv = port.readcoo(os.path.join(golden_dir, "mlp_fc1_weight.mtx"))
+        return 64, 784, 100, (ar, ac, av), (bc, br, bv)
+    n, rows, cols, vals = gen.rmat_coo(10, 16, "g500", seed=1, dtype=dt)
+    return n, n, n, (rows, cols, vals), (rows, cols, vals)
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("case", ["c1", "rect", "cancel", "mlp", "rmat10"])
+def test_reference_variants_agree(port, golden_dir, case, dt):
+    """Four formulations inside the reference -- the outer product (cscMulcsr), the outer product through the raw
+    compact form, the row-wise product through csr2compact, and the merge tree (multHardware + six layers of merge2way,
+    scheduled by merge()) -- and the plain-C restatement all give the same matrix: indices identical, values within
+    rounding (the merge tree adds in tree order, deduplicateCOO in std::sort's order, the restatement in ascending k)."""
+    M, K, N, a, b = _variant_inputs(golden_dir, port, case, dt)
+    want, csx = spgemm_from_coo(port, M, K, N, a, b, dt)
+    rows = csr_rows(want["rowptr"])
+    ref = orc.ref(dt)
+    tol = 2e-5 if dt == np.float32 else 1e-12
+    seen = 0
+    for name in ref.VARIANTS:
+        rc, got = ref.spgemm_variant(name, M, K, *csx)
+        if rc == 6:   # the reference's merge() asserts on this input (longest row of A a multiple of 63 beyond 64)
+            assert name == "csr2compact+merge"
+            continue
+        assert rc == 0, (name, rc)
+        assert got["partials"] == want["partials"], name
+        assert np.array_equal(got["rows"], rows) and np.array_equal(got["cols"], want["colidx"]), name
+        scale = np.maximum(np.abs(want["vals"]), np.finfo(dt).tiny)
+        if case == "mlp":      # terms of both signs: the error scales with the terms, not with their sum
+            scale = np.maximum(scale, np.abs(want["vals"]).max())
+        if case == "cancel":   # an exact zero that must stay: 1*2 + 2*(-1)
+            assert np.array_equal(got["vals"], want["vals"]), name
+        else:
+            assert np.all(np.abs(got["vals"] - want["vals"]) <= tol * scale), name
+        seen += 1
+    assert seen >= 3
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built (needs /root/reference at build time)")
+def test_reference_merge_tree_refuses_what_the_reference_asserts_on(port):
+    """merge() starts with mergeK = ways % 63 (SimSpGEMM.cpp:457): 126 streams -> 0 -> its own assert (:483) fails.
+    The driver reports that input instead of aborting the test process."""
+    K = 126
+    a = (np.zeros(K, np.uint32), np.arange(K, dtype=np.uint32), np.ones(K))       # one row of A with 126 non-zeros
+    a = (np.concatenate([a[0], [1]]).astype(np.uint32), np.concatenate([a[1], [0]]).astype(np.uint32), np.ones(K + 1))
+    b = (np.arange(K, dtype=np.uint32), np.arange(K, dtype=np.uint32) % 5, np.ones(K))
+    _, csx = spgemm_from_coo(port, 2, K, 5, a, b, np.float64)
+    rc, _ = orc.ref(np.float64).spgemm_variant("csr2compact+merge", 2, K, *csx)
+    assert rc == 6
+    rc, got = orc.ref(np.float64).spgemm_variant("csr2compact+compactMulcsr", 2, K, *csx)
+    assert rc == 0 and got["partials"] == K + 1
