@@ -6,7 +6,8 @@
  *
  *   reference interface                                         replaced by
  *   ----------------------------------------------------------  -----------------------------
- *   CSRMatrix{pos,data{idx,val}}            common.h:10-16,39-47  SoA arrays (ptr/idx/val)
+ *   CSRMatrix{pos,data{idx,val}}            common.h:10-16,39-47  SoA arrays (ptr/idx/val); the reference's own AoS
+ *                                                                 layout is taken as it stands by osp_spgemm_csc_csr_aos
  *   std::vector<COOMatrix> cscMulcsr(csc, csr)
  *                                           SimSpGEMM.cpp:265-281  osp_spgemm_csc_csr (multiply)
  *   COOMatrix deduplicateCOO(coo)           SimSpGEMM.cpp:519-535  osp_spgemm_csc_csr (merge)
@@ -112,6 +113,11 @@ int osp_context_create_on_stream(int device, void *hip_stream, osp_context_t *ct
 int osp_context_destroy(osp_context_t ctx);
 /* Return pooled device memory to the driver. */
 int osp_context_trim(osp_context_t ctx);
+/* Device memory from / back to the context's buffer pool (the same pool the products take their staging buffers from).
+ * The multi-GPU exchange receives into such buffers, so that the memory a finished local product has just released is
+ * reused instead of being allocated a second time next to the pool.  No reference counterpart. */
+int osp_context_alloc(osp_context_t ctx, uint64_t bytes, void **device_ptr);
+int osp_context_free(osp_context_t ctx, void *device_ptr);
 void osp_config_default(osp_config_t *cfg);
 const char *osp_last_error_string(void);
 const char *osp_status_string(int status);
@@ -129,6 +135,19 @@ int osp_spgemm_csc_csr(osp_context_t ctx, osp_dtype_t dtype, uint64_t M, uint64_
                        const int64_t *a_colptr, const uint32_t *a_rowidx, const void *a_vals,
                        const int64_t *b_rowptr, const uint32_t *b_colidx, const void *b_vals,
                        osp_memspace_t space, const osp_config_t *cfg, osp_result_t *result);
+
+/*
+ * The same product on the reference's IN-MEMORY layout, with no conversion on the caller's side:
+ *   CSRMatrix{ std::vector<size_t> pos; std::vector<CSRElement{index_t idx; value_t val}> data; }   common.h:10-16,39-47
+ * a_pos / b_pos = csc.pos.data() / csr.pos.data() (K+1 offsets of 64 bits, size_t on every LP64 host), a_data / b_data
+ * = csc.data.data() / csr.data.data(): PACKED records {u32 idx; T val} -- 8 bytes for value_t = float (the reference as
+ * it ships, common.h:8), 12 bytes for double (`#pragma pack(push, 1)`, common.h:10).  The records are copied to the
+ * device as they are and split into index / value arrays there; everything else is osp_spgemm_csc_csr.
+ * Drop-in for `cscMulcsr(csc, csr)` (SimSpGEMM.cpp:265) + deduplicateCOO (:519).
+ */
+int osp_spgemm_csc_csr_aos(osp_context_t ctx, osp_dtype_t dtype, uint64_t M, uint64_t K, uint64_t N,
+                           const uint64_t *a_pos, const void *a_data, const uint64_t *b_pos, const void *b_data,
+                           osp_memspace_t space, const osp_config_t *cfg, osp_result_t *result);
 
 /*
  * The same product, STREAMED: output rows are merged in consecutive row panels (the library's unit of work when the

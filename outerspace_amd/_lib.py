@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libouterspace_spgemm.so")
+# OSP_LIBRARY=<path> loads another build of the same ABI (`make debug` / `make ballot` write files of their own, so the
+# default name is always the product build)
+LIB_PATH = os.environ.get("OSP_LIBRARY") or os.path.join(_HERE, "libouterspace_spgemm.so")
 
 OSP_F32, OSP_F64 = 0, 1
 OSP_HOST, OSP_DEVICE = 0, 1
@@ -61,7 +63,7 @@ PANEL_FN = C.CFUNCTYPE(C.c_int, C.POINTER(Panel), C.c_void_p)
 EXPORTS = [
     "osp_context_create", "osp_context_create_on_stream", "osp_context_destroy", "osp_context_trim",
     "osp_config_default", "osp_last_error_string", "osp_status_string", "osp_spgemm_csc_csr", "osp_spgemm_csc_csr_panels",
-    "osp_spgemm_coo",
+    "osp_spgemm_coo", "osp_spgemm_csc_csr_aos", "osp_context_alloc", "osp_context_free",
     "osp_merge_csr_parts", "osp_result_info", "osp_result_copy_csr", "osp_result_device_ptrs",
     "osp_result_destroy", "osp_mtx_read", "osp_host_free", "osp_coo_to_compressed_f32",
     "osp_coo_to_compressed_f64", "osp_spgemm_mtx", "osp_result_write_mtx",
@@ -96,6 +98,9 @@ def lib():
     L.osp_context_create_on_stream.argtypes = [i32, vp, C.POINTER(vp)]
     L.osp_context_destroy.argtypes = [vp]
     L.osp_context_trim.argtypes = [vp]
+    L.osp_context_alloc.argtypes = [vp, u64, C.POINTER(vp)]
+    L.osp_context_free.argtypes = [vp, vp]
+    L.osp_spgemm_csc_csr_aos.argtypes = [vp, i32, u64, u64, u64, vp, vp, vp, vp, i32, C.POINTER(Config), C.POINTER(vp)]
     L.osp_config_default.argtypes = [C.POINTER(Config)]
     L.osp_config_default.restype = None
     L.osp_spgemm_csc_csr.argtypes = [vp, i32, u64, u64, u64, vp, vp, vp, vp, vp, vp, i32,

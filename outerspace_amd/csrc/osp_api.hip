@@ -24,17 +24,7 @@
 
 namespace osp {
 
-thread_local std::string g_last_error;
-
-int fail(int status, const char *fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_last_error = buf;
-    return status;
-}
+// (fail() and the per-thread error string live in osp_host.cpp, the host-only TU)
 
 #define OSP_HIP(expr)                                                                      \
     do {                                                                                   \
@@ -267,6 +257,18 @@ struct PhaseTimer {
         return t;
     }
 };
+// start / stop events of one call, released on every exit path
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    EventPair() {
+        OSP_HIP(hipEventCreate(&a));
+        if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); throw Error(OSP_ERR_HIP, "hipEventCreate failed"); }
+    }
+    ~EventPair() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+    EventPair(const EventPair &) = delete;
+    EventPair &operator=(const EventPair &) = delete;
+    float ms() const { float t = 0; (void)hipEventElapsedTime(&t, a, b); return t; }
+};
 enum { PH_SYM = 0, PH_MUL = 1, PH_MERGE = 2, PH_COMPACT = 3, PH_MUL_K = 4, PH_MERGE_K = 5, PH_SPLIT_K = 6 };
 
 // debugging aid: OSP_SYNC=1 waits for the stream at the marked points of a product and names them on stderr, so
@@ -330,49 +332,72 @@ static inline int bits_for(uint64_t n) {  // bits needed to represent values in 
     return b;
 }
 
-// Host <-> device copies go through a pinned staging buffer owned by this library, never straight from or to the
-// caller's pageable memory: hipMemcpyAsync on pageable memory pins and unpins the caller's pages on the fly, and
-// round 1 saw intermittent "Memory access fault by GPU" aborts on HOST addresses in exactly the runs that passed host
-// operands (pytest, the gloo rehearsal) and never in the ones that passed device pointers (bench.py).
+// Host <-> device copies go through two pinned staging buffers owned by this library (the memcpy into one overlaps the
+// DMA out of the other) rather than straight from or to the caller's pageable memory.  Kept for what it guarantees, not
+// for a fault it avoids (round 1's intermittent GPU fault had another cause): the caller's pages are
+// never pinned or unpinned behind its back, the copy is complete when the call returns, and the pinned footprint is two
+// 16 MB chunks whatever the operand size.  Device-resident operands (bench.py, the multi-GPU path) never come here.
+constexpr size_t kStageChunk = 16u << 20;
 struct Pinned {
-    char *p = nullptr;
-    size_t bytes = 0;
-    char *get(size_t want) {
-        if (bytes < want) {
-            if (p) (void)hipHostFree(p);
-            p = nullptr;
-            bytes = 0;
-            if (hipHostMalloc((void **)&p, want, hipHostMallocDefault) != hipSuccess) {
-                (void)hipGetLastError();
-                throw Error(OSP_ERR_ALLOC, "hipHostMalloc of the staging buffer failed");
-            }
-            bytes = want;
+    char *p = nullptr;     // two halves of `half` bytes each
+    size_t half = 0;
+    hipEvent_t done[2] = {nullptr, nullptr};  // the DMA out of / into half i has finished
+    // (never freed: a thread_local destructor can run after the HIP runtime has shut down)
+    void reserve(size_t want) {
+        want = std::min(std::max<size_t>(want, 64), kStageChunk);
+        if (!done[0]) { OSP_HIP(hipEventCreateWithFlags(&done[0], hipEventDisableTiming)); OSP_HIP(hipEventCreateWithFlags(&done[1], hipEventDisableTiming)); }
+        if (half >= want) return;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        half = 0;
+        if (hipHostMalloc((void **)&p, 2 * want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            throw Error(OSP_ERR_ALLOC, "hipHostMalloc of the staging buffer failed");
         }
-        return p;
+        half = want;
     }
 };
 static Pinned &pinned_buffer() {
-    static thread_local Pinned b;  // lives as long as the thread; a few MB
+    static thread_local Pinned b;  // lives as long as the thread; at most 32 MB
     return b;
 }
-constexpr size_t kStageChunk = 16u << 20;
 static void copy_h2d(void *dst, const void *src, size_t bytes, hipStream_t s) {
-    char *pin = pinned_buffer().get(std::min(bytes, kStageChunk));
-    for (size_t off = 0; off < bytes; off += kStageChunk) {
-        const size_t n = std::min(kStageChunk, bytes - off);
-        memcpy(pin, (const char *)src + off, n);
-        OSP_HIP(hipMemcpyAsync((char *)dst + off, pin, n, hipMemcpyHostToDevice, s));
-        OSP_HIP(hipStreamSynchronize(s));  // the one staging buffer is reused by the next chunk
+    if (!bytes) return;
+    Pinned &pb = pinned_buffer();
+    pb.reserve(bytes);
+    const size_t chunk = pb.half;
+    int i = 0;
+    size_t nchunks = 0;
+    for (size_t off = 0; off < bytes; off += chunk, i ^= 1, nchunks++) {
+        const size_t n = std::min(chunk, bytes - off);
+        if (nchunks >= 2) OSP_HIP(hipEventSynchronize(pb.done[i]));  // the DMA that last read this half
+        memcpy(pb.p + i * chunk, (const char *)src + off, n);
+        OSP_HIP(hipMemcpyAsync((char *)dst + off, pb.p + i * chunk, n, hipMemcpyHostToDevice, s));
+        OSP_HIP(hipEventRecord(pb.done[i], s));
     }
+    OSP_HIP(hipStreamSynchronize(s));  // complete on return: the staging halves are free again
 }
 static void copy_d2h(void *dst, const void *src, size_t bytes, hipStream_t s) {
-    char *pin = pinned_buffer().get(std::min(std::max<size_t>(bytes, 64), kStageChunk));
-    for (size_t off = 0; off < bytes; off += kStageChunk) {
-        const size_t n = std::min(kStageChunk, bytes - off);
-        OSP_HIP(hipMemcpyAsync(pin, (const char *)src + off, n, hipMemcpyDeviceToHost, s));
-        OSP_HIP(hipStreamSynchronize(s));
-        memcpy((char *)dst + off, pin, n);
+    if (!bytes) return;
+    Pinned &pb = pinned_buffer();
+    pb.reserve(bytes);
+    const size_t chunk = pb.half;
+    // DMA of chunk j+1 runs while chunk j is copied out of its half
+    size_t off_prev = 0, n_prev = 0;
+    int i = 0;
+    bool have_prev = false;
+    for (size_t off = 0; off < bytes; off += chunk, i ^= 1) {
+        const size_t n = std::min(chunk, bytes - off);
+        OSP_HIP(hipMemcpyAsync(pb.p + i * chunk, (const char *)src + off, n, hipMemcpyDeviceToHost, s));
+        OSP_HIP(hipEventRecord(pb.done[i], s));
+        if (have_prev) {
+            OSP_HIP(hipEventSynchronize(pb.done[i ^ 1]));
+            memcpy((char *)dst + off_prev, pb.p + (i ^ 1) * chunk, n_prev);
+        }
+        off_prev = off; n_prev = n; have_prev = true;
     }
+    OSP_HIP(hipEventSynchronize(pb.done[i ^ 1]));
+    memcpy((char *)dst + off_prev, pb.p + (i ^ 1) * chunk, n_prev);
 }
 template <class T> static T d2h(const T *dptr, hipStream_t s) {
     T v;
@@ -855,10 +880,8 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
     PhaseTimer tm(s);
-    hipEvent_t ev0, ev1;
-    OSP_HIP(hipEventCreate(&ev0));
-    OSP_HIP(hipEventCreate(&ev1));
-    OSP_HIP(hipEventRecord(ev0, s));
+    EventPair ev;
+    OSP_HIP(hipEventRecord(ev.a, s));
 
     // pointer arrays first: nnz comes from their last entries
     const int64_t *a_colptr = to_device(sc, a_colptr_in, K + 1, space, s);
@@ -1018,10 +1041,9 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     merge_pipeline<T>(ctx, res, prod, M, N, row_off, P_rows, cfg.partial_capacity, tm, r_lo, r_hi, off_lo, sink,
                       rowwise ? &ct : nullptr);
 
-    OSP_HIP(hipEventRecord(ev1, s));
+    OSP_HIP(hipEventRecord(ev.b, s));
     OSP_HIP(hipStreamSynchronize(s));
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    const float ms = ev.ms();
     if (getenv("OSP_VERBOSE")) {
         fprintf(stderr, "[osp] product done in %.1f ms; pool misses so far: %llu hipMalloc calls, %.1f GB, %.1f ms\n", ms,
                 (unsigned long long)ctx->malloc_calls, ctx->malloc_bytes / 1e9, ctx->malloc_ms);
@@ -1034,8 +1056,6 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     res->info.ms_multiply_kernel = tm.total(PH_MUL_K);
     res->info.ms_merge_kernel = tm.total(PH_MERGE_K);
     res->info.ms_split_kernel = tm.total(PH_SPLIT_K);
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
 }
 
 // COO (device arrays, any order) -> compressed by `seg` with ascending `inner` indices; all outputs in `sc`.
@@ -1077,10 +1097,8 @@ static void spgemm_coo_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, u
                             const T *b_vals, osp_memspace_t space, const osp_config_t &cfg) {
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
-    hipEvent_t ev0, ev1;
-    OSP_HIP(hipEventCreate(&ev0));
-    OSP_HIP(hipEventCreate(&ev1));
-    OSP_HIP(hipEventRecord(ev0, s));
+    EventPair ev;
+    OSP_HIP(hipEventRecord(ev.a, s));
     const uint32_t *ar = to_device(sc, a_rows, nnz_a, space, s), *ac = to_device(sc, a_cols, nnz_a, space, s);
     const uint32_t *br = to_device(sc, b_rows, nnz_b, space, s), *bc = to_device(sc, b_cols, nnz_b, space, s);
     const T *av = to_device(sc, a_vals, nnz_a, space, s), *bv = to_device(sc, b_vals, nnz_b, space, s);
@@ -1089,16 +1107,47 @@ static void spgemm_coo_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, u
     T *acv, *bcv;
     coo_to_compressed_device<T>(ctx, sc, K, M, nnz_a, ac, ar, av, "A (COO)", &ap, &ai, &acv);  // csc = coo2csr<true>(A, K)
     coo_to_compressed_device<T>(ctx, sc, K, N, nnz_b, br, bc, bv, "B (COO)", &bp, &bi, &bcv);  // csr = coo2csr(B, K)
-    OSP_HIP(hipEventRecord(ev1, s));
+    OSP_HIP(hipEventRecord(ev.b, s));
     osp_config_t c2 = cfg;
     c2.validate = 0;  // ordering, ranges and duplicates were just established
     spgemm_impl<T>(ctx, res, M, K, N, ap, ai, acv, bp, bi, bcv, OSP_DEVICE, c2);
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    const float ms = ev.ms();
     res->info.ms_ingest = ms;
     res->info.ms_total += ms;
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
+}
+
+// The reference's in-memory operands as they stand (osp_spgemm_csc_csr_aos): packed {u32 idx; T val} records -- the
+// layout of Part<T> -- are split into index and value arrays on the device.
+template <class T>
+__global__ void aos_unpack_kernel(const Part<T> *__restrict__ data, uint64_t n, uint32_t *__restrict__ idx, T *__restrict__ val) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PartWords<T> r = load_part_words(data + i);
+    idx[i] = r.col();
+    val[i] = r.val();
+}
+template <class T>
+static void spgemm_aos_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint64_t N, const uint64_t *a_pos, const void *a_data,
+                            const uint64_t *b_pos, const void *b_data, osp_memspace_t space, const osp_config_t &cfg) {
+    static_assert(sizeof(Part<T>) == 4 + sizeof(T), "Part<T> must be the reference's packed CSRElement (common.h:10-16)");
+    hipStream_t s = ctx->stream;
+    Scratch sc(ctx);
+    // size_t offsets are taken as int64 (same bits below 2^63; larger values fail the pointer check)
+    const int64_t *ap = to_device(sc, (const int64_t *)a_pos, K + 1, space, s);
+    const int64_t *bp = to_device(sc, (const int64_t *)b_pos, K + 1, space, s);
+    int64_t nnz_a, nnz_b;
+    if (space == OSP_HOST) { nnz_a = (int64_t)a_pos[K]; nnz_b = (int64_t)b_pos[K]; }
+    else { nnz_a = d2h(ap + K, s); nnz_b = d2h(bp + K, s); }
+    if (nnz_a < 0 || nnz_b < 0 || (uint64_t)nnz_a >= 0xffffffffull || (uint64_t)nnz_b >= 0xffffffffull)
+        throw Error(OSP_ERR_ARG, "operands with >= 2^32 non-zeros are not supported");
+    if ((nnz_a && !a_data) || (nnz_b && !b_data)) throw Error(OSP_ERR_ARG, "null data array");
+    const Part<T> *ad = to_device(sc, (const Part<T> *)a_data, (uint64_t)nnz_a, space, s);
+    const Part<T> *bd = to_device(sc, (const Part<T> *)b_data, (uint64_t)nnz_b, space, s);
+    uint32_t *ai = sc.get<uint32_t>(nnz_a), *bi = sc.get<uint32_t>(nnz_b);
+    T *av = sc.get<T>(nnz_a), *bv = sc.get<T>(nnz_b);
+    if (nnz_a) aos_unpack_kernel<T><<<grid_for(nnz_a, 256), 256, 0, s>>>(ad, (uint64_t)nnz_a, ai, av);
+    if (nnz_b) aos_unpack_kernel<T><<<grid_for(nnz_b, 256), 256, 0, s>>>(bd, (uint64_t)nnz_b, bi, bv);
+    spgemm_impl<T>(ctx, res, M, K, N, ap, ai, av, bp, bi, bv, OSP_DEVICE, cfg);
 }
 
 template <class T>
@@ -1108,10 +1157,8 @@ static void merge_parts_impl(Context *ctx, Result *res, uint64_t M, uint64_t N, 
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
     PhaseTimer tm(s);
-    hipEvent_t ev0, ev1;
-    OSP_HIP(hipEventCreate(&ev0));
-    OSP_HIP(hipEventCreate(&ev1));
-    OSP_HIP(hipEventRecord(ev0, s));
+    EventPair ev;
+    OSP_HIP(hipEventRecord(ev.a, s));
     std::vector<const int64_t *> rp(nparts);
     std::vector<const uint32_t *> ci(nparts);
     std::vector<const T *> va(nparts);
@@ -1149,11 +1196,9 @@ static void merge_parts_impl(Context *ctx, Result *res, uint64_t M, uint64_t N, 
     prod.ctx = ctx; prod.d_rowptrs = d_rp; prod.d_colidxs = d_ci; prod.d_valss = d_va;
     prod.nparts = nparts; prod.row_off = row_off;
     merge_pipeline<T>(ctx, res, prod, M, N, row_off, P, cfg.partial_capacity, tm);
-    OSP_HIP(hipEventRecord(ev1, s));
+    OSP_HIP(hipEventRecord(ev.b, s));
     OSP_HIP(hipStreamSynchronize(s));
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, ev0, ev1);
-    res->info.ms_total = ms;
+    res->info.ms_total = ev.ms();
     res->info.ms_symbolic = tm.total(PH_SYM);
     res->info.ms_multiply = tm.total(PH_MUL);
     res->info.ms_merge = tm.total(PH_MERGE);
@@ -1161,8 +1206,6 @@ static void merge_parts_impl(Context *ctx, Result *res, uint64_t M, uint64_t N, 
     res->info.ms_multiply_kernel = tm.total(PH_MUL_K);
     res->info.ms_merge_kernel = tm.total(PH_MERGE_K);
     res->info.ms_split_kernel = tm.total(PH_SPLIT_K);
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
 }
 
 static void destroy_result(Result *r) {
@@ -1188,8 +1231,6 @@ using namespace osp;
     catch (const std::exception &e) { return fail(OSP_ERR_HIP, "%s", e.what()); }
 
 extern "C" {
-
-const char *osp_last_error_string(void) { return g_last_error.c_str(); }
 
 const char *osp_status_string(int st) {
     switch (st) {
@@ -1258,6 +1299,21 @@ int osp_context_trim(osp_context_t c) {
     ((Context *)c)->trim();
     return OSP_OK;
 }
+int osp_context_alloc(osp_context_t c_, uint64_t bytes, void **device_ptr) {
+    Context *c = (Context *)c_;
+    if (!c || !device_ptr) return fail(OSP_ERR_ARG, "null argument");
+    OSP_GUARD_BEGIN
+    OSP_HIP(hipSetDevice(c->device));
+    *device_ptr = c->alloc((size_t)bytes);
+    return OSP_OK;
+    OSP_GUARD_END
+}
+int osp_context_free(osp_context_t c_, void *device_ptr) {
+    Context *c = (Context *)c_;
+    if (!c) return fail(OSP_ERR_ARG, "null context");
+    c->release(device_ptr);
+    return OSP_OK;
+}
 int osp_context_destroy(osp_context_t c_) {
     Context *c = (Context *)c_;
     if (!c) return OSP_OK;
@@ -1294,6 +1350,38 @@ int osp_spgemm_csc_csr(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, uint64
         else
             spgemm_impl<double>(ctx, res, M, K, N, a_colptr, a_rowidx, (const double *)a_vals, b_rowptr, b_colidx,
                                 (const double *)b_vals, space, cfg);
+    } catch (const Error &e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        destroy_result(res);
+        return fail(e.status, "%s", e.what());
+    } catch (const std::exception &e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        destroy_result(res);
+        return fail(OSP_ERR_ALLOC, "%s", e.what());
+    }
+    *result = (osp_result_t)res;
+    return OSP_OK;
+}
+
+int osp_spgemm_csc_csr_aos(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, uint64_t K, uint64_t N, const uint64_t *a_pos,
+                           const void *a_data, const uint64_t *b_pos, const void *b_data, osp_memspace_t space,
+                           const osp_config_t *cfg_, osp_result_t *result) {
+    Context *ctx = (Context *)ctx_;
+    if (!ctx || !result) return fail(OSP_ERR_ARG, "null context or result pointer");
+    if (!a_pos || !b_pos) return fail(OSP_ERR_ARG, "null pointer array");
+    if (dtype != OSP_F32 && dtype != OSP_F64) return fail(OSP_ERR_ARG, "dtype must be OSP_F32 or OSP_F64");
+    if (space != OSP_HOST && space != OSP_DEVICE) return fail(OSP_ERR_ARG, "bad memory space");
+    if (M >= 0xffffffffull || N > 0xffffffffull || K >= 0xffffffffull) return fail(OSP_ERR_ARG, "dimension exceeds the u32 index type");
+    osp_config_t cfg;
+    if (cfg_) cfg = *cfg_; else osp_config_default(&cfg);
+    Result *res = new Result;
+    res->ctx = ctx;
+    res->dtype = dtype;
+    res->info.M = M; res->info.K = K; res->info.N = N; res->info.dtype = dtype;
+    try {
+        OSP_HIP(hipSetDevice(ctx->device));
+        if (dtype == OSP_F32) spgemm_aos_impl<float>(ctx, res, M, K, N, a_pos, a_data, b_pos, b_data, space, cfg);
+        else spgemm_aos_impl<double>(ctx, res, M, K, N, a_pos, a_data, b_pos, b_data, space, cfg);
     } catch (const Error &e) {
         (void)hipStreamSynchronize(ctx->stream);
         destroy_result(res);

@@ -14,73 +14,113 @@
 #include "../../include/outerspace_spgemm.h"
 #include "osp_internal.h"
 
+#include <cstdarg>
+#include <string>
+
+namespace osp {
+// last error of the calling thread (osp_last_error_string); shared with osp_api.hip through osp_internal.h
+thread_local std::string g_last_error;
+int fail(int status, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return status;
+}
+}  // namespace osp
+
 using osp::fail;
 
 extern "C" {
 
 void osp_host_free(void *p) { free(p); }
+const char *osp_last_error_string(void) { return osp::g_last_error.c_str(); }
 
 int osp_mtx_read(const char *path, int symmetric, uint64_t *nrow, uint64_t *ncol, uint64_t *nnz,
                  uint32_t **rows, uint32_t **cols, double **vals) {
     if (!path || !nrow || !ncol || !nnz || !rows || !cols || !vals) return fail(OSP_ERR_ARG, "null argument");
+    *rows = nullptr; *cols = nullptr; *vals = nullptr;
+    *nrow = *ncol = *nnz = 0;
     FILE *f = fopen(path, "rb");
     if (!f) return fail(OSP_ERR_IO, "cannot open %s", path);
-    std::vector<uint32_t> r, c;
-    std::vector<double> v;
     char *line = nullptr;
-    size_t cap = 0;
-    bool header = true;
-    unsigned long long NR = 0, NC = 0, NZ = 0;
-    while (getline(&line, &cap, f) >= 0) {
-        // skip rule of the reference (:66-77): first non-blank char is '%', or nothing but blanks
-        const char *p = line;
-        while (*p == ' ' || *p == '\t') p++;
-        if (*p == '%' || *p == '\0' || *p == '\n' || *p == '\r') continue;
-        if (header) {  // :79-88
-            sscanf(p, "%llu %llu %llu", &NR, &NC, &NZ);
-            r.reserve(symmetric ? 2 * NZ : NZ);
-            c.reserve(symmetric ? 2 * NZ : NZ);
-            v.reserve(symmetric ? 2 * NZ : NZ);
-            header = false;
-            continue;
-        }
-        // "row col [val]"; strtoull/strtod instead of sscanf: same accepted syntax, much faster
-        char *end = nullptr;
-        unsigned long long row = strtoull(p, &end, 10);
-        unsigned long long col = 0;
-        double val = 1.0;  // pattern entry (:92-93)
-        if (end != p) {
-            const char *q = end;
-            col = strtoull(q, &end, 10);
-            if (end != q) {
-                q = end;
-                double t = strtod(q, &end);
-                if (end != q) val = t;
+    int st = OSP_OK;
+    try {  // nothing thrown by the vectors may cross the C boundary
+        std::vector<uint32_t> r, c;
+        std::vector<double> v;
+        size_t cap = 0;
+        bool header = true;
+        unsigned long long NR = 0, NC = 0, NZ = 0;
+        // an entry takes at least four bytes of the file ("1 1\n"): a header that announces more than the file can hold
+        // (or garbage) must not drive the reservation
+        unsigned long long file_bytes = 0;
+        if (fseek(f, 0, SEEK_END) == 0) { const long e = ftell(f); if (e > 0) file_bytes = (unsigned long long)e; }
+        rewind(f);
+        while (getline(&line, &cap, f) >= 0) {
+            // skip rule of the reference (:66-77): first non-blank char is '%', or nothing but blanks
+            const char *p = line;
+            while (*p == ' ' || *p == '\t') p++;
+            if (*p == '%' || *p == '\0' || *p == '\n' || *p == '\r') continue;
+            if (header) {  // :79-88
+                sscanf(p, "%llu %llu %llu", &NR, &NC, &NZ);
+                const unsigned long long want = std::min(NZ, file_bytes / 4 + 1) * (symmetric ? 2ull : 1ull);
+                r.reserve(want);
+                c.reserve(want);
+                v.reserve(want);
+                header = false;
+                continue;
+            }
+            // "row col [val]"; strtoull/strtod instead of sscanf: same accepted syntax, much faster
+            char *end = nullptr;
+            unsigned long long row = strtoull(p, &end, 10);
+            unsigned long long col = 0;
+            double val = 1.0;  // pattern entry (:92-93)
+            if (end != p) {
+                const char *q = end;
+                col = strtoull(q, &end, 10);
+                if (end != q) {
+                    q = end;
+                    double t = strtod(q, &end);
+                    if (end != q) val = t;
+                }
+            }
+            r.push_back((uint32_t)(row - 1));  // 1-based -> 0-based (:94)
+            c.push_back((uint32_t)(col - 1));
+            v.push_back(val);
+            if (symmetric && row != col) {  // :95-96
+                r.push_back((uint32_t)(col - 1));
+                c.push_back((uint32_t)(row - 1));
+                v.push_back(val);
             }
         }
-        r.push_back((uint32_t)(row - 1));  // 1-based -> 0-based (:94)
-        c.push_back((uint32_t)(col - 1));
-        v.push_back(val);
-        if (symmetric && row != col) {  // :95-96
-            r.push_back((uint32_t)(col - 1));
-            c.push_back((uint32_t)(row - 1));
-            v.push_back(val);
+        const size_t n = r.size();
+        *rows = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+        *cols = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+        *vals = (double *)malloc((n ? n : 1) * sizeof(double));
+        if (!*rows || !*cols || !*vals) {
+            st = fail(OSP_ERR_ALLOC, "host allocation failed");
+        } else {
+            if (n) {
+                memcpy(*rows, r.data(), n * sizeof(uint32_t));
+                memcpy(*cols, c.data(), n * sizeof(uint32_t));
+                memcpy(*vals, v.data(), n * sizeof(double));
+            }
+            *nrow = NR; *ncol = NC; *nnz = n;
         }
+    } catch (const std::bad_alloc &) {
+        st = fail(OSP_ERR_ALLOC, "host allocation failed while reading %s", path);
+    } catch (const std::exception &e) {
+        st = fail(OSP_ERR_ALLOC, "%s while reading %s", e.what(), path);
     }
     free(line);
     fclose(f);
-    const size_t n = r.size();
-    *rows = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
-    *cols = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
-    *vals = (double *)malloc((n ? n : 1) * sizeof(double));
-    if (!*rows || !*cols || !*vals) return fail(OSP_ERR_ALLOC, "host allocation failed");
-    if (n) {
-        memcpy(*rows, r.data(), n * sizeof(uint32_t));
-        memcpy(*cols, c.data(), n * sizeof(uint32_t));
-        memcpy(*vals, v.data(), n * sizeof(double));
+    if (st != OSP_OK) {  // hand nothing half-made to the caller
+        free(*rows); free(*cols); free(*vals);
+        *rows = nullptr; *cols = nullptr; *vals = nullptr;
     }
-    *nrow = NR; *ncol = NC; *nnz = n;
-    return OSP_OK;
+    return st;
 }
 
 }  // extern "C"
@@ -125,6 +165,7 @@ int coo_to_compressed(int by_col, uint64_t nseg, uint64_t nnz, const uint32_t *r
     return OSP_OK;
 }
 
+#ifndef OSP_HOST_ONLY  // (the sanitizer build of the host-only code leaves out what calls the GPU entry points)
 template <class T>
 int spgemm_mtx_t(osp_context_t ctx, osp_dtype_t dtype, const char *pa, const char *pb, int transpose_b,
                  const osp_config_t *cfg, osp_result_t *result) {
@@ -156,6 +197,7 @@ int spgemm_mtx_t(osp_context_t ctx, osp_dtype_t dtype, const char *pa, const cha
     return st;
 }
 
+#endif
 }  // namespace
 
 extern "C" {
@@ -171,6 +213,7 @@ int osp_coo_to_compressed_f64(int by_col, uint64_t nseg, uint64_t nnz, const uin
     catch (const std::exception &e) { return fail(OSP_ERR_ALLOC, "%s", e.what()); }
 }
 
+#ifndef OSP_HOST_ONLY
 int osp_spgemm_mtx(osp_context_t ctx, osp_dtype_t dtype, const char *path_a, const char *path_b, int transpose_b,
                    const osp_config_t *cfg, osp_result_t *result) {
     if (!ctx || !path_a || !path_b || !result) return fail(OSP_ERR_ARG, "null argument");
@@ -208,5 +251,7 @@ int osp_result_write_mtx(osp_result_t r, const char *path) {
     } catch (const std::exception &e) { return fail(OSP_ERR_ALLOC, "%s", e.what()); }
     return OSP_OK;
 }
+
+#endif  // OSP_HOST_ONLY
 
 }  // extern "C"

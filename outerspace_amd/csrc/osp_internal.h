@@ -12,6 +12,7 @@ struct Error : std::exception {
     const char *what() const noexcept override { return msg.c_str(); }
 };
 
+extern thread_local std::string g_last_error;
 // Records the message for osp_last_error_string() and returns `status`.
 int fail(int status, const char *fmt, ...);
 

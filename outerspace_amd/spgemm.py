@@ -84,6 +84,11 @@ class CsrResult:
 ALGORITHMS = {"outer": 0, "rowwise": 1}  # osp_algorithm_t
 
 
+def aos_dtype(value_dtype):
+    """numpy view of the reference's packed ``CSRElement{index_t idx; value_t val}`` (``common.h:10-16``)."""
+    return np.dtype([("idx", "<u4"), ("val", np.dtype(value_dtype).newbyteorder("<"))], align=False)
+
+
 class Context:
     """One GPU + one HIP stream + a buffer pool (``osp_context_t``)."""
 
@@ -153,6 +158,34 @@ class Context:
         _lib.check(_lib.lib().osp_spgemm_csc_csr(self._h, _DT[dt], M, K, N, *[_ptr(a) for a in arrs],
                                                  _lib.OSP_HOST, C.byref(cfg), C.byref(h)))
         return CsrResult(self, h)
+
+    def spgemm_csc_csr_aos(self, M, K, N, a_pos, a_data, b_pos, b_data, *, validate=True, partial_capacity=0):
+        """The reference's in-memory operands as they stand (``osp_spgemm_csc_csr_aos``): ``pos`` = ``CSRMatrix::pos``
+        (K+1 uint64 offsets), ``data`` = ``CSRMatrix::data`` as a packed structured array ``aos_dtype(value dtype)`` =
+        ``[('idx', '<u4'), ('val', '<f4' | '<f8')]`` (``common.h:10-16``: 8 or 12 bytes per record)."""
+        vdt = np.dtype(a_data.dtype.fields["val"][0])
+        want = aos_dtype(vdt)
+        if a_data.dtype != want or b_data.dtype != want:
+            raise TypeError(f"data arrays must both have dtype {want}")
+        ap, bp = np.ascontiguousarray(a_pos, np.uint64), np.ascontiguousarray(b_pos, np.uint64)
+        if len(ap) != K + 1 or len(bp) != K + 1:
+            raise OspError(_lib.ERR_DIM, f"pos arrays must have K+1={K + 1} entries (got {len(ap)} and {len(bp)})")
+        ad, bd = np.ascontiguousarray(a_data), np.ascontiguousarray(b_data)
+        cfg = self._config(validate, partial_capacity, None)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().osp_spgemm_csc_csr_aos(self._h, _DT[vdt], M, K, N, _ptr(ap), _ptr(ad), _ptr(bp), _ptr(bd),
+                                                     _lib.OSP_HOST, C.byref(cfg), C.byref(h)))
+        return CsrResult(self, h)
+
+    def alloc(self, nbytes):
+        """Device memory from the context's buffer pool (``osp_context_alloc``); give it back with ``free``."""
+        p = C.c_void_p()
+        _lib.check(_lib.lib().osp_context_alloc(self._h, int(nbytes), C.byref(p)))
+        return p.value or 0
+
+    def free(self, ptr):
+        if self._h is not None and ptr:
+            _lib.check(_lib.lib().osp_context_free(self._h, C.c_void_p(int(ptr))))
 
     def spgemm_coo(self, M, K, N, a, b, *, partial_capacity=0):
         """C = A * B from COO triples a = (rows, cols, vals), b = (rows, cols, vals) in any order (numpy, host):

@@ -98,3 +98,38 @@ def test_host_conversion_matches_reference_golden(golden_dir):
         b = S.coo_to_csr(7, g["rect_b_rows"], g["rect_b_cols"], g["rect_b_vals"].astype(dt))
         for got, key in zip((*a, *b), ("apos", "aidx", "aval", "bpos", "bidx", "bval")):
             assert np.array_equal(got, g[f"rect_{key}_{s}"]), key
+
+
+def test_host_layer_under_sanitizers(golden_dir, tmp_path):
+    """the host C++ layer (reader, COO -> CSC/CSR, the CLI's host parts) and the plain-C oracle under
+    AddressSanitizer + UBSan.  `make asan` builds tests/asan_host_driver.cpp with osp_host.cpp and oracle_spgemm.c;
+    the driver feeds them the golden files and hostile inputs (huge header counts, garbage, megabyte lines) and compares
+    product and oracle; a sanitizer report aborts it.  CPU only -- GPU sanitizers are not available on this pool."""
+    import subprocess
+    csrc = os.path.join(ROOT, "outerspace_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "asan"], check=True, stdout=subprocess.DEVNULL)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(ROOT, "outerspace_amd", "osp_host_asan_test"), golden_dir, str(tmp_path)],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
+
+
+def test_cli_under_sanitizers_fails_cleanly_without_gpu(golden_dir, tmp_path):
+    """The CLI built with ASan/UBSan against the real library: usage error, unreadable file, and -- where there is no GPU --
+    a clean "no CPU path" failure at context creation instead of a fallback."""
+    import subprocess
+    import torch
+    csrc = os.path.join(ROOT, "outerspace_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "asan"], check=True, stdout=subprocess.DEVNULL)
+    exe = os.path.join(ROOT, "outerspace_amd", "osp_spgemm_asan")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")  # (the HIP runtime keeps process-lifetime allocations)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 2 and "usage" in r.stderr
+    r = subprocess.run([exe, str(tmp_path / "nope.mtx"), str(tmp_path / "nope.mtx")], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 1 and "cannot open" in r.stderr and "AddressSanitizer" not in r.stderr
+    if not torch.cuda.is_available():
+        a = os.path.join(golden_dir, "c1_A.mtx")
+        r = subprocess.run([exe, a, os.path.join(golden_dir, "c1_B.mtx")], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 1 and "no CPU path" in r.stderr and "NNZ = 410" in r.stdout
+        assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr

@@ -492,3 +492,186 @@ def test_streamed_panels_equal_the_resident_product(ctx, port):
     seen = []
     info = ctx.spgemm_csc_csr_panels(np.float64, n, n, n, [z.data_ptr(), e.data_ptr(), e.data_ptr()] * 2, lambda p: seen.append(dict(p)))
     assert info["nnz_c"] == 0 and len(seen) == 1 and (seen[0]["row_begin"], seen[0]["row_end"], seen[0]["nnz"]) == (0, n, 0)
+
+
+# ---- the reference's in-memory layout, the binding a maintainer would add, the buffer pool -------------------------------
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_aos_entry_point_takes_the_reference_layout(ctx, port, dt):
+    """osp_spgemm_csc_csr_aos: CSRMatrix{vector<size_t> pos; vector<CSRElement{idx,val}> data} (common.h:10-16,39-47) as
+    it stands -- packed 8 / 12-byte records, unsigned 64-bit offsets.  Same bits as the SoA call and the oracle."""
+    from outerspace_amd import spgemm as S
+    n, rows, cols, vals = gen.rmat_coo(11, 12, "g500", seed=12, dtype=dt)
+    acsc, bcsr = S.coo_to_csc(n, rows, cols, vals), S.coo_to_csr(n, rows, cols, vals)
+    rec = S.aos_dtype(dt)
+    assert rec.itemsize == 4 + np.dtype(dt).itemsize
+    ad, bd = np.empty(len(rows), rec), np.empty(len(rows), rec)
+    ad["idx"], ad["val"], bd["idx"], bd["val"] = acsc[1], acsc[2], bcsr[1], bcsr[2]
+    got = ctx.spgemm_csc_csr_aos(n, n, n, acsc[0].astype(np.uint64), ad, bcsr[0].astype(np.uint64), bd)
+    want = port.spgemm(n, n, n, *acsc, *bcsr)
+    assert_same(got, want)
+    # a duplicate inside a column is the reference's 233 here too; an empty product works
+    bad = ad.copy()
+    j = int(np.flatnonzero(np.diff(acsc[0]) >= 2)[0])
+    bad["idx"][acsc[0][j] + 1] = bad["idx"][acsc[0][j]]
+    with pytest.raises(S.OspError) as ei:
+        ctx.spgemm_csc_csr_aos(n, n, n, acsc[0].astype(np.uint64), bad, bcsr[0].astype(np.uint64), bd)
+    assert ei.value.status == 233
+    z = np.zeros(5, np.uint64)
+    assert ctx.spgemm_csc_csr_aos(3, 4, 6, z, np.empty(0, rec), z, np.empty(0, rec)).nnz == 0
+
+
+@pytest.mark.parametrize("sfx,flag", [("f32", []), ("f64", [])])
+def test_reference_code_calls_the_library_through_the_binding(golden_dir, sfx, flag):
+    """oracle/_ref/binding_demo_*: the reference's own readcoo / coo2csr / cscMulcsr / deduplicateCOO (compiled from its
+    text in the build container) next to integration/simspgemm_gpu_binding.h -- the drop-in of INTEGRATION.md section 2 --
+    on the configs[0] files: the GPU result must match the reference's CPU result."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", f"binding_demo_{sfx}")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/binding_demo_* not built (needs /root/reference at build time)")
+    for a, b in (("c1_A.mtx", "c1_B.mtx"), ("mlp_act.mtx", "mlp_fc1_weight.mtx")):
+        r = subprocess.run([exe, os.path.join(golden_dir, a), os.path.join(golden_dir, b)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "MATCH:" in r.stdout, r.stdout + r.stderr
+    assert "mul flops ref = 39574" in r.stdout   # mulflops_ref of the MLP layer (mlp_expected.npz: P)
+
+
+def test_pool_buffers_for_the_exchange(ctx):
+    """osp_context_alloc / osp_context_free: device memory out of the context's pool, usable from torch zero-copy, and
+    handed back to the pool (the multi-GPU exchange receives into such buffers)."""
+    import torch
+    from outerspace_amd.distributed import _as_tensor
+    dev = torch.device("cuda", 0)
+    p = ctx.alloc(1 << 20)
+    assert p and p % 256 == 0
+    t = _as_tensor(p, 1 << 18, "<i4", dev, torch.int32)
+    t.copy_(torch.arange(1 << 18, dtype=torch.int32, device=dev))
+    assert int(t.sum()) == (1 << 18) * ((1 << 18) - 1) // 2
+    ctx.free(p)
+    q = ctx.alloc(1 << 20)     # best fit: the block just released
+    assert q == p
+    ctx.free(q)
+    assert ctx.alloc(0)        # a zero-byte request still yields a valid (minimal) block
+
+
+# ---- BASELINE configs[1] and configs[2] at their full sizes ----------------------------------------------------------------
+_FULL = {}
+
+
+def _bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("osp_bench", os.path.join(root, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_webgoogle_shape_full_size_vs_oracle(ctx, port):
+    """configs[1] at its full size: the 916 428-vertex web-Google-shaped pattern matrix of bench.py (nnz ~5.2 M, P ~54 M,
+    nnz(C) ~43 M; the real SuiteSparse file is not available offline), whole self-product against the plain-C oracle:
+    rowptr / colidx / values bit for bit."""
+    import torch
+    from outerspace_amd.distributed import _as_tensor
+    dev = torch.device("cuda", 0)
+    if "web" not in _FULL:
+        n, csr, csc = _bench_module().webgoogle_device(1, dev, torch.float64)
+        host = [t.cpu().numpy() for t in (*csc, *csr)]
+        host = [a.view(np.uint32) if a.dtype == np.int32 else a for a in host]
+        _FULL["web"] = (n, csr, csc, port.spgemm(n, n, n, *host))
+    n, csr, csc, want = _FULL["web"]
+    assert n == 916428 and want["partials"] > 50_000_000
+    res = ctx.spgemm_csc_csr_device(np.float64, n, n, n, [t.data_ptr() for t in (*csc, *csr)], validate=True)
+    assert res.info["partials"] == want["partials"] and res.nnz == len(want["colidx"])
+    rp, ci, va = res.device_ptrs()
+    assert torch.equal(_as_tensor(rp, n + 1, "<i8", dev, torch.int64), torch.from_numpy(want["rowptr"]).to(dev))
+    assert torch.equal(_as_tensor(ci, res.nnz, "<i4", dev, torch.int32), torch.from_numpy(want["colidx"].view(np.int32)).to(dev))
+    assert torch.equal(_as_tensor(va, res.nnz, "<f8", dev, torch.float64), torch.from_numpy(want["vals"]).to(dev))
+    res.close()
+
+
+def test_rmat22_full_size_properties_and_slab_parity(ctx, port):
+    """configs[2] at its full size (R-MAT scale 22, edge factor 16, (a,b,c,d) = (.45,.22,.22,.11), seed 1: nnz 67 M,
+    P = 1.19e10, nnz(C) = 1.15e10 -- 138 GB of CSR, far beyond what the oracle can form):
+      * size-independent properties of the WHOLE result, checked on the device: rowptr monotone and ending at nnz,
+        columns strictly ascending inside every row, row sums C*1 = A*(B*1), total 1^T C 1 = (1^T A)(B 1);
+      * linearity: the product of (2A) and B, streamed panel by panel, is exactly 2C with the same structure;
+      * parity proper on a k-slab: columns [0, k1) of A times rows [0, k1) of B (about 6e7 partial products, the
+        unit a k-shard computes) against the oracle, bit for bit."""
+    import torch
+    from outerspace_amd.distributed import _as_tensor
+    dev = torch.device("cuda", 0)
+    if "rmat22" not in _FULL:
+        _FULL["rmat22"] = _bench_module().rmat_device(22, 16, gen.RMAT_PRESETS["mild"], 1, dev, torch.float64)
+    n, csr, csc = _FULL["rmat22"]
+    ptrs = [t.data_ptr() for t in (*csc, *csr)]
+    # ---- slab parity against the oracle ----
+    w = (csc[0][1:] - csc[0][:-1]) * (csr[0][1:] - csr[0][:-1])
+    k1 = int(torch.searchsorted(torch.cumsum(w, 0), torch.tensor([60_000_000], device=dev))[0]) + 1
+    ea, eb = int(csc[0][k1]), int(csr[0][k1])
+    host = [csc[0][:k1 + 1].cpu().numpy(), csc[1][:ea].cpu().numpy().view(np.uint32), csc[2][:ea].cpu().numpy(),
+            csr[0][:k1 + 1].cpu().numpy(), csr[1][:eb].cpu().numpy().view(np.uint32), csr[2][:eb].cpu().numpy()]
+    want = port.spgemm(n, k1, n, *host)
+    res = ctx.spgemm_csc_csr_device(np.float64, n, n, n, ptrs, k_range=(0, k1))
+    assert res.info["partials"] == want["partials"] and res.nnz == len(want["colidx"])
+    rp, ci, va = res.device_ptrs()
+    assert torch.equal(_as_tensor(rp, n + 1, "<i8", dev, torch.int64), torch.from_numpy(want["rowptr"]).to(dev))
+    assert torch.equal(_as_tensor(ci, res.nnz, "<i4", dev, torch.int32), torch.from_numpy(want["colidx"].view(np.int32)).to(dev))
+    assert torch.equal(_as_tensor(va, res.nnz, "<f8", dev, torch.float64), torch.from_numpy(want["vals"]).to(dev))
+    res.close()
+    del want, host
+    # ---- the whole product ----
+    res = ctx.spgemm_csc_csr_device(np.float64, n, n, n, ptrs)
+    nnz = res.nnz
+    assert res.info["partials"] == int(w.sum()) and nnz > 11_000_000_000
+    rp, ci, va = res.device_ptrs()
+    rowptr = _as_tensor(rp, n + 1, "<i8", dev, torch.int64)
+    colidx = _as_tensor(ci, nnz, "<i4", dev, torch.int32)
+    vals = _as_tensor(va, nnz, "<f8", dev, torch.float64)
+    assert int(rowptr[0]) == 0 and int(rowptr[-1]) == nnz and bool((rowptr[1:] >= rowptr[:-1]).all())
+    b1 = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(
+        0, torch.repeat_interleave(torch.arange(n, device=dev), csr[0][1:] - csr[0][:-1]), csr[2])          # B * 1
+    want_rowsum = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, csc[1].long(), csc[2] * torch.repeat_interleave(
+        b1, csc[0][1:] - csc[0][:-1]))                                                                       # A * (B * 1)
+    got_rowsum = torch.zeros(n, dtype=torch.float64, device=dev)
+    CH = 1 << 28
+    for lo in range(0, nnz, CH):
+        hi = min(lo + CH, nnz)
+        pos = torch.arange(lo, hi, device=dev)
+        rows = torch.searchsorted(rowptr, pos, right=True) - 1
+        got_rowsum.index_add_(0, rows, vals[lo:hi])
+        # strictly ascending columns inside a row: col[i] > col[i-1] unless i starts a row
+        if hi - lo > 1:
+            c = colidx[lo:hi].long() & 0xffffffff
+            same_row = rows[1:] == rows[:-1]
+            assert bool((c[1:][same_row] > c[:-1][same_row]).all()), "columns must ascend strictly inside every row"
+        if lo:  # the pair across the chunk boundary
+            r_prev = int(torch.searchsorted(rowptr, torch.tensor([lo - 1], device=dev), right=True)[0]) - 1
+            if r_prev == int(rows[0]):
+                assert int(colidx[lo]) & 0xffffffff > int(colidx[lo - 1]) & 0xffffffff
+        del pos, rows
+    assert torch.allclose(got_rowsum, want_rowsum, rtol=1e-9, atol=0)
+    assert abs(float(got_rowsum.sum()) - float(want_rowsum.sum())) <= 1e-9 * float(want_rowsum.sum())
+    del got_rowsum, want_rowsum, b1
+    # ---- linearity, streamed: (2A) * B == 2 * C exactly, panel by panel against the resident result ----
+    a2 = csc[2] * 2.0
+    seen = {"rows": 0, "nnz": 0}
+
+    def on_panel(p):
+        lo = int(rowptr[p["row_begin"]])
+        nr = p["row_end"] - p["row_begin"]
+        assert p["nnz"] == int(rowptr[p["row_end"]]) - lo
+        prp = _as_tensor(p["rowptr"], nr + 1, "<i8", dev, torch.int64)
+        assert torch.equal(prp, rowptr[p["row_begin"]:p["row_end"] + 1] - lo)
+        for s0 in range(0, p["nnz"], CH):
+            s1 = min(s0 + CH, p["nnz"])
+            assert torch.equal(_as_tensor(p["colidx"] + 4 * s0, s1 - s0, "<i4", dev, torch.int32), colidx[lo + s0:lo + s1])
+            assert torch.equal(_as_tensor(p["vals"] + 8 * s0, s1 - s0, "<f8", dev, torch.float64), vals[lo + s0:lo + s1] * 2.0)
+        seen["rows"] += nr
+        seen["nnz"] += p["nnz"]
+    info = ctx.spgemm_csc_csr_panels(np.float64, n, n, n, [csc[0].data_ptr(), csc[1].data_ptr(), a2.data_ptr(), *ptrs[3:]], on_panel)
+    assert seen["rows"] == n and seen["nnz"] == nnz == info["nnz_c"] and info["panels"] >= 2
+    res.close()
+    del rowptr, colidx, vals, a2
+    ctx.trim()
+    torch.cuda.empty_cache()
