@@ -4,7 +4,8 @@ No reference counterpart -- the reference is one process, one thread (SURVEY.md 
 Shape of the computation (BASELINE.json north_star):
 
 1. The shared dimension k is cut into ``world`` contiguous slabs of (nearly) equal partial-product
-   count.  Rank g runs the single-GPU pipeline on its slab -> a partial CSR ``C_g`` over ALL rows.
+   count.  Rank g holds ONLY its slab -- columns [k_g, k_g+1) of A, rows [k_g, k_g+1) of B (``slice_k_slab``) --
+   and runs the single-GPU pipeline on it -> a partial CSR ``C_g`` over ALL rows.
 2. One exchange step.  Output rows are cut into ``world`` contiguous ranges balanced by
    ``sum_g nnz(C_g[row])`` (one small all-reduce of per-row counts).  Because a CSR is row-major, the
    rows a rank owes to rank h are ONE contiguous slice of its colidx / vals arrays, so the exchange
@@ -86,18 +87,26 @@ def all_to_all_v(dst, src, recv_l, send_l, dist, world, group=None, max_bytes=No
                 o0 += o.numel()
 
 
-def exchange_partial_csr(rowptr, colidx, vals, dist, world, group=None):
+def exchange_partial_csr(rowptr, colidx, vals, dist, world, group=None, ncols=None, alloc=None, stats=None):
     """All-to-all-v of a partial CSR (all M rows) so that rank h ends up with every rank's rows of range h.
 
     rowptr int64 [M+1], colidx int32 [nnz], vals [nnz] -- torch tensors on the communication device.
+    ncols: number of columns of the matrix (bounds a row's entry count; None = unknown).
+    alloc(numel, like) -> 1-D tensor for the two large receive buffers (default torch.empty); the GPU path hands out
+    memory of the library's pool, so that what the local product has just released is reused.
+    stats (dict, optional) receives bytes_sent (payload this rank sends to OTHER ranks) and row_bounds.
     Returns (row_bounds, parts) where parts[g] = (rowptr_g int64 [nr+1], colidx_g, vals_g) for the rows
     [row_bounds[rank], row_bounds[rank+1]) as computed by rank g.
     """
     rank = dist.get_rank(group)
     M = rowptr.numel() - 1
-    rownnz = (rowptr[1:] - rowptr[:-1]).to(torch.int32)
-    weight = rownnz.clone()
-    dist.all_reduce(weight, group=group)  # sum over ranks of per-row nnz (fits int32: asserted by caller sizes)
+    # a row of one rank's partial CSR holds at most ncols entries, the per-row sum over the ranks at most world * ncols:
+    # 32-bit counts only where both are known to fit
+    cnt_dtype = torch.int32 if (ncols is not None and int(ncols) < (1 << 31)) else torch.int64
+    rownnz = (rowptr[1:] - rowptr[:-1]).to(cnt_dtype)
+    wide = ncols is None or world * int(ncols) >= (1 << 31)
+    weight = rownnz.to(torch.int64) if wide else rownnz.clone()
+    dist.all_reduce(weight, group=group)  # sum over ranks of per-row nnz
     rb = plan_row_ranges(weight, world)
     rb_t = torch.tensor(rb, device=rowptr.device, dtype=torch.int64)
     offs = rowptr[rb_t]                                   # element offset of each range in my arrays
@@ -109,12 +118,19 @@ def exchange_partial_csr(rowptr, colidx, vals, dist, world, group=None):
     nr = rb[rank + 1] - rb[rank]
     row_send = [rb[h + 1] - rb[h] for h in range(world)]
     # per-row counts of my range as computed by every rank
-    cnt_recv = torch.empty(nr * world, dtype=torch.int32, device=rowptr.device)
+    cnt_recv = torch.empty(nr * world, dtype=cnt_dtype, device=rowptr.device)
     all_to_all_v(cnt_recv, rownnz, [nr] * world, row_send, dist, world, group)
-    col_recv = torch.empty(sum(recv_l), dtype=colidx.dtype, device=colidx.device)
-    val_recv = torch.empty(sum(recv_l), dtype=vals.dtype, device=vals.device)
+    if alloc is None:
+        alloc = lambda numel, like: torch.empty(numel, dtype=like.dtype, device=like.device)
+    col_recv = alloc(sum(recv_l), colidx)
+    val_recv = alloc(sum(recv_l), vals)
     all_to_all_v(col_recv, colidx, recv_l, send_l, dist, world, group)
     all_to_all_v(val_recv, vals, recv_l, send_l, dist, world, group)
+    if stats is not None:
+        away = sum(send_l) - send_l[rank]
+        stats["bytes_sent"] = (away * (colidx.element_size() + vals.element_size()) + rownnz.element_size() * (M - row_send[rank])
+                               + 8 * (world - 1))
+        stats["row_bounds"] = list(rb)
     parts, o = [], 0
     for g in range(world):
         rp = torch.zeros(nr + 1, dtype=torch.int64, device=rowptr.device)
@@ -124,11 +140,14 @@ def exchange_partial_csr(rowptr, colidx, vals, dist, world, group=None):
     return rb, parts
 
 
-def k_sharded_product(local_product, merge_parts, k_bounds, dist, world, group=None, sync=None):
+def k_sharded_product(local_product, merge_parts, k_bounds, dist, world, group=None, sync=None, ncols=None, alloc=None,
+                      after_exchange=None, stats=None):
     """Generic driver: local slab product -> exchange -> local merge.
 
     local_product(k0, k1) -> (rowptr, colidx, vals) tensors (partial CSR over all rows)
     merge_parts(nrows, parts) -> (rowptr, colidx, vals) of the summed CSR
+    after_exchange() (optional) runs once the exchange has completed: the place to release the local partial CSR before
+    the final merge allocates (at 2 GPUs and scale 22 both do not fit side by side).
     Returns dict(row_bounds, rowptr, colidx, vals, seconds=(local, exchange, merge)).
     """
     rank = dist.get_rank(group)
@@ -137,9 +156,12 @@ def k_sharded_product(local_product, merge_parts, k_bounds, dist, world, group=N
     if sync:
         sync()
     t1 = time.perf_counter()
-    rb, parts = exchange_partial_csr(rowptr, colidx, vals, dist, world, group)
+    rb, parts = exchange_partial_csr(rowptr, colidx, vals, dist, world, group, ncols=ncols, alloc=alloc, stats=stats)
     if sync:
         sync()
+    del rowptr, colidx, vals
+    if after_exchange:
+        after_exchange()
     t2 = time.perf_counter()
     out = merge_parts(rb[rank + 1] - rb[rank], parts)
     if sync:
@@ -161,28 +183,54 @@ def _as_tensor(ptr, n, typestr, device, dtype):
     return torch.as_tensor(_DevArray(ptr, n, typestr), device=device)
 
 
-def spgemm_k_sharded(ctx, np_dtype, M, K, N, csc, csr, k_bounds, dist, rank, world, partial_capacity=0,
-                     stage_through_host=False, checksum=False):
-    """The GPU instantiation used by bench.py.  csc/csr: (ptr int64, idx int32, vals) CUDA tensors holding
-    the FULL operands on every rank (each rank touches only its k slab).  Returns an info dict.
+def slice_k_slab(csc, csr, k0, k1):
+    """The operands of one k shard: columns [k0,k1) of A (CSC) and rows [k0,k1) of B (CSR) as arrays of their own
+    (pointers rebased to 0) -- all a rank of the k-sharded product holds ("only its columns of A and rows
+    of B").  csc / csr: (ptr int64, idx int32, vals) tensors.  Returns (K', csc', csr')."""
+    def cut(t):
+        ptr, idx, val = t
+        e0, e1 = int(ptr[k0]), int(ptr[k1])
+        return ((ptr[k0:k1 + 1] - e0).contiguous(), idx[e0:e1].clone(), val[e0:e1].clone())
+    return k1 - k0, cut(csc), cut(csr)
+
+
+def spgemm_k_sharded(ctx, np_dtype, M, N, slab, dist, rank, world, partial_capacity=0, stage_through_host=False, checksum=False,
+                     fetch=False):
+    """The GPU instantiation used by bench.py.  slab = slice_k_slab(...) of THIS rank: (K', csc', csr') CUDA tensors.
+    Returns an info dict (the local product's counters plus the exchange / final-merge figures); fetch=True adds
+    info["final_csr"] = this rank's rows of C as host arrays (rowptr, colidx, vals) -- tests only.
+
+    Memory: the exchange receives into buffers of the library's pool (the staging memory the local product has just given
+    back), and the local partial CSR is released as soon as the exchange has completed, before the final merge allocates.
 
     stage_through_host=True moves the exchanged arrays through host memory so that the whole path can
     be rehearsed with the `gloo` backend (e.g. several ranks sharing one GPU); the product path over
     RCCL keeps everything in HBM."""
+    Ks, csc, csr = slab
     device = csc[0].device
     ptrs = [t.data_ptr() for t in (*csc, *csr)]
     vt = "<f8" if np.dtype(np_dtype) == np.float64 else "<f4"
     tdt = torch.float64 if np.dtype(np_dtype) == np.float64 else torch.float32
-    keep = {}
+    keep, pooled, stats = {}, [], {}
 
-    def local_product(k0, k1):
-        res = ctx.spgemm_csc_csr_device(np_dtype, M, K, N, ptrs, validate=False, partial_capacity=partial_capacity,
-                                        k_range=(k0, k1))
+    def local_product(_k0, _k1):
+        res = ctx.spgemm_csc_csr_device(np_dtype, M, Ks, N, ptrs, validate=False, partial_capacity=partial_capacity)
         keep["local"] = res
+        keep["local_info"] = dict(res.info)
         rp, ci, va = res.device_ptrs()
         out = (_as_tensor(rp, M + 1, "<i8", device, torch.int64), _as_tensor(ci, res.nnz, "<i4", device, torch.int32),
                _as_tensor(va, res.nnz, vt, device, tdt))
         return tuple(t.cpu() for t in out) if stage_through_host else out
+
+    def pool_alloc(numel, like):
+        if stage_through_host or numel == 0:
+            return torch.empty(numel, dtype=like.dtype, device=like.device)
+        p = ctx.alloc(numel * like.element_size())
+        pooled.append(p)
+        return _as_tensor(p, numel, {torch.int32: "<i4", torch.float32: "<f4", torch.float64: "<f8"}[like.dtype], device, like.dtype)
+
+    def release_local():
+        keep.pop("local").close()
 
     def merge_parts(nrows, parts):
         if stage_through_host:
@@ -194,27 +242,37 @@ def spgemm_k_sharded(ctx, np_dtype, M, K, N, csc, csr, k_bounds, dist, rank, wor
         keep["final"] = res
         return res.device_ptrs()
 
-    out = k_sharded_product(local_product, merge_parts, k_bounds, dist, world, sync=torch.cuda.synchronize)
-    info = dict(keep["local"].info)
-    fin = keep["final"].info
-    tot = torch.tensor([fin["nnz_c"], info["partials"]], device="cpu" if stage_through_host else device, dtype=torch.int64)
-    dist.all_reduce(tot)
-    info.update(nnz_c_global=int(tot[0]), partials_global=int(tot[1]), nnz_c_final_local=fin["nnz_c"],
-                ms_local=out["seconds"][0] * 1e3, ms_exchange=out["seconds"][1] * 1e3,
-                ms_final_merge=out["seconds"][2] * 1e3, final_merge_partials=fin["partials"])
-    if checksum:  # sum of all values of C (all ranks), for the 1^T C 1 = (1^T A)(B 1) sanity check
-        _, _, va = keep["final"].device_ptrs()
-        vs = _as_tensor(va, fin["nnz_c"], vt, device, tdt).sum(dtype=torch.float64).reshape(1)
-        vs = vs.cpu() if stage_through_host else vs
-        dist.all_reduce(vs)
-        info["val_sum_global"] = float(vs[0])
-    keep["local"].close()
-    keep["final"].close()
-    return info
+    try:
+        out = k_sharded_product(local_product, merge_parts, [0] * (rank + 1) + [Ks] * (world - rank), dist, world,
+                                sync=torch.cuda.synchronize, ncols=N, alloc=pool_alloc, after_exchange=release_local, stats=stats)
+        info = keep["local_info"]
+        fin = keep["final"].info
+        tot = torch.tensor([fin["nnz_c"], info["partials"]], device="cpu" if stage_through_host else device, dtype=torch.int64)
+        dist.all_reduce(tot)
+        info.update(nnz_c_global=int(tot[0]), partials_global=int(tot[1]), nnz_c_final_local=fin["nnz_c"],
+                    ms_local=out["seconds"][0] * 1e3, ms_exchange=out["seconds"][1] * 1e3,
+                    ms_final_merge=out["seconds"][2] * 1e3, final_merge_partials=fin["partials"],
+                    bytes_sent=stats.get("bytes_sent", 0), row_bounds=stats.get("row_bounds"))
+        if checksum:  # sum of all values of C (all ranks), for the 1^T C 1 = (1^T A)(B 1) sanity check
+            _, _, va = keep["final"].device_ptrs()
+            vs = _as_tensor(va, fin["nnz_c"], vt, device, tdt).sum(dtype=torch.float64).reshape(1)
+            vs = vs.cpu() if stage_through_host else vs
+            dist.all_reduce(vs)
+            info["val_sum_global"] = float(vs[0])
+        if fetch:
+            info["final_csr"] = keep["final"].to_host()
+        return info
+    finally:
+        for r in ("local", "final"):
+            if r in keep:
+                keep[r].close()
+        keep.clear()
+        for p in pooled:
+            ctx.free(p)
 
 
 def spgemm_row_sharded(ctx, np_dtype, M, K, N, ptrs, dist, rank, world, device, partial_capacity=0, host_collectives=False,
-                       checksum=False):
+                       checksum=False, fetch=False):
     """Row-sharded product: rank i computes the i-th of `world` output-row ranges (balanced by partial products, derived
     by every rank from the replicated operands alone).  No data-path collective; only the counters of the report are
     all-reduced.  ptrs: the six device addresses of CSC(A) / CSR(B)."""
@@ -233,5 +291,7 @@ def spgemm_row_sharded(ctx, np_dtype, M, K, N, ptrs, dist, rank, world, device, 
         vs = vs.cpu() if host_collectives else vs
         dist.all_reduce(vs)
         info["val_sum_global"] = float(vs[0])
+    if fetch:
+        info["final_csr"] = res.to_host()
     res.close()
     return info
