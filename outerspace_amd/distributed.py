@@ -105,7 +105,7 @@ def exchange_partial_csr(rowptr, colidx, vals, dist, world, group=None, ncols=No
     cnt_dtype = torch.int32 if (ncols is not None and int(ncols) < (1 << 31)) else torch.int64
     rownnz = (rowptr[1:] - rowptr[:-1]).to(cnt_dtype)
     wide = ncols is None or world * int(ncols) >= (1 << 31)
-    weight = rownnz.to(torch.int64) if wide else rownnz.clone()
+    weight = rownnz.to(torch.int64).clone() if wide else rownnz.clone()   # (all_reduce works in place: never on rownnz itself)
     dist.all_reduce(weight, group=group)  # sum over ranks of per-row nnz
     rb = plan_row_ranges(weight, world)
     rb_t = torch.tensor(rb, device=rowptr.device, dtype=torch.int64)
