@@ -43,6 +43,9 @@ struct Context {
     std::map<void *, size_t> live;
     size_t pooled_bytes = 0;
     uint32_t cus = 256;  // persistent kernels size their grids from this
+    // stable radix ranks from the return order of LDS atomics (true) or from ballot matching (false): decided when the
+    // context is created (self-test; OSP_RANK=ballot|atomic overrides), see osp_prims.h
+    bool rank_atomic = OSP_RANK_ATOMIC != 0;
     // pool misses (OSP_VERBOSE prints them per product): device allocations are slow, a product should not need any
     // once the pool is warm
     uint64_t malloc_calls = 0, malloc_bytes = 0;
@@ -405,6 +408,13 @@ template <class T> static T d2h(const T *dptr, hipStream_t s) {
     return v;
 }
 
+// run `stmt` with RA = the context's ranking variant as a compile-time constant
+#define OSP_WITH_RA(ctx_, ...)                                               \
+    do {                                                                     \
+        if ((ctx_)->rank_atomic) { constexpr bool RA = true; __VA_ARGS__; }  \
+        else { constexpr bool RA = false; __VA_ARGS__; }                     \
+    } while (0)
+
 // Where the partial products of a panel come from.
 template <class T> struct Producer {
     virtual ~Producer() {}
@@ -516,8 +526,8 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         uint8_t *vfirst = sc.get<uint8_t>(nvirt + 1);
         // rows up to kSplitRowMax: one workgroup each (histogram, scan and scatter in one kernel)
         tm.begin(PH_SPLIT_K);
-        split_row_kernel<T><<<nlong, kSplitThreads, 0, s>>>(p0.long_rows, nlong, hbits, nstretch, vbase, hoff, io.row_off, base, colbits,
-                                                            io.stage, qstage, vrow_off);
+        OSP_WITH_RA(ctx, split_row_kernel<T, RA><<<nlong, kSplitThreads, 0, s>>>(p0.long_rows, nlong, hbits, nstretch, vbase, hoff, io.row_off,
+                                                                                 base, colbits, io.stage, qstage, vrow_off));
         tm.end(PH_SPLIT_K);
         res->info.split_launches++;
         res->info.split_partials += nh - std::min<uint64_t>(nh, nblocks * (uint64_t)kSplitJob);
@@ -526,8 +536,8 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
             split_count_kernel<<<(unsigned)nblocks, kSplitThreads, 0, s>>>(p0.long_rows, nlong, blkbase, hbase, hbits, nstretch, io.row_off,
                                                                          base, colbits, (const char *)io.stage, (uint32_t)sizeof(Part<T>), ghist);
             device_exclusive_scan<LoadU32, uint32_t>(LoadU32{ghist}, ncell, ghist, ghist_tmp, s);
-            split_scatter_kernel<T><<<(unsigned)nblocks, kSplitThreads, 0, s>>>(p0.long_rows, nlong, blkbase, hbase, hbits, nstretch,
-                                                                              io.row_off, base, colbits, io.stage, ghist, hoff, qstage);
+            OSP_WITH_RA(ctx, split_scatter_kernel<T, RA><<<(unsigned)nblocks, kSplitThreads, 0, s>>>(
+                                 p0.long_rows, nlong, blkbase, hbase, hbits, nstretch, io.row_off, base, colbits, io.stage, ghist, hoff, qstage));
         }
         dbg_sync(s, "split: stretch rows");
         split_vrows_kernel<<<grid_for(nvirt + 1, 256), 256, 0, s>>>(nlong, vbase, hbase, nstretch, ghist, hoff, nvirt, nh, vrow_off, vfirst);
@@ -562,8 +572,9 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
                 uint32_t *bticket = sc.get<uint32_t>(1);
                 OSP_HIP(hipMemsetAsync(bticket, 0, sizeof(uint32_t), s));
                 const uint32_t bgrid = ctx->cus * (uint32_t)merge_wgs_per_cu<T, kBigTileThreads, kBigTileCap>();
-                merge_tiles_kernel<T, kBigTileThreads, 32, kBigTileCap><<<std::min<uint32_t>(nmid, bgrid), kBigTileThreads, 0, s>>>(
-                    bdesc, nmid, lv, colbits, nullptr, bticket, nullptr, nullptr, nullptr, nullptr);
+                OSP_WITH_RA(ctx, merge_tiles_kernel<T, kBigTileThreads, 32, kBigTileCap, kMergeMaxWgs, RA>
+                            <<<std::min<uint32_t>(nmid, bgrid), kBigTileThreads, 0, s>>>(bdesc, nmid, lv, colbits, nullptr, bticket, nullptr, nullptr,
+                                                                                         nullptr, nullptr));
             }
             dbg_sync(s, "over-long segments: big in-place tiles");
             if (nhuge) {
@@ -579,7 +590,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
                 uint32_t *hist_tmp = sc.get<uint32_t>(scan_scratch_entries(sort_hist_entries(ns)));
                 heavy_fill_kernel<<<grid_for(ns, 256), 256, 0, s>>>(huge_list, soff, nhuge, vrow_off, 0, colbits, (const char *)qstage,
                                                                     (uint32_t)sizeof(Part<T>), ns, keys[0], poss[0]);
-                const int cur = device_radix_sort_pairs<uint64_t>(keys, poss, ns, colbits + bits_for(nhuge), hist, hist_tmp, s);
+                const int cur = device_radix_sort_pairs<uint64_t>(keys, poss, ns, colbits + bits_for(nhuge), hist, hist_tmp, s, ctx->rank_atomic);
                 T *sorted_val = sc.get<T>(ns);
                 heavy_gather_kernel<T><<<grid_for(ns, 256), 256, 0, s>>>(poss[cur], qstage, ns, sorted_val);
                 uint64_t *headscan = sc.get<uint64_t>(ns + 1);
@@ -621,12 +632,14 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
     // persistent workgroups: as many as the LDS lets run at once
     if (io.ct.enabled) {
         const uint32_t rw_grid = ctx->cus * (uint32_t)merge_wgs_per_cu<T, kMergeThreads, TileCap<T>::value, kMergeMaxWgs, 64>();
-        merge_tiles_kernel<T, kMergeThreads, 64><<<std::min<uint32_t>(ntot, rw_grid), kMergeThreads, 0, s>>>(
-            desc, ntot, lv, colbits, tile_status, ticket, io.out_in, io.c_col, io.c_val, io.out_out, io.ct);
+        OSP_WITH_RA(ctx, merge_tiles_kernel<T, kMergeThreads, 64, TileCap<T>::value, kMergeMaxWgs, RA>
+                    <<<std::min<uint32_t>(ntot, rw_grid), kMergeThreads, 0, s>>>(desc, ntot, lv, colbits, tile_status, ticket, io.out_in, io.c_col,
+                                                                                 io.c_val, io.out_out, io.ct));
     } else {
         const uint32_t merge_grid = ctx->cus * (uint32_t)merge_wgs_per_cu<T, kMergeThreads, TileCap<T>::value>();
-        merge_tiles_kernel<T, kMergeThreads><<<std::min<uint32_t>(ntot, merge_grid), kMergeThreads, 0, s>>>(
-            desc, ntot, lv, colbits, tile_status, ticket, io.out_in, io.c_col, io.c_val, io.out_out);
+        OSP_WITH_RA(ctx, merge_tiles_kernel<T, kMergeThreads, 0, TileCap<T>::value, kMergeMaxWgs, RA>
+                    <<<std::min<uint32_t>(ntot, merge_grid), kMergeThreads, 0, s>>>(desc, ntot, lv, colbits, tile_status, ticket, io.out_in, io.c_col,
+                                                                                    io.c_val, io.out_out));
     }
     tm.end(PH_MERGE_K);
     dbg_sync(s, "merge tiles");
@@ -1009,7 +1022,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         uint32_t *bs = rowwise ? ss.get<uint32_t>(nnz) : nullptr;
         sym_chunk_len_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(a_colptr, b_rowptr, k0, k1, e0, nnz, w, bs);
         device_sort_rows<SymEpilogue>(a_rowidx + e0, nnz, std::max(1, bits_for(M)), ka, pa, kb, pb, hist, hist_tmp,
-                                      SymEpilogue{w, bs, rows_sorted, perm, w_sorted, bs_sorted}, s);
+                                      SymEpilogue{w, bs, rows_sorted, perm, w_sorted, bs_sorted}, s, ctx->rank_atomic);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{w_sorted}, nnz, offs_sorted, scan_tmp, s);
         sym_row_offsets_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(rows_sorted, offs_sorted, nnz, M, row_off, rowfirst);
         const uint64_t rw_cap = rowwise ? (uint64_t)TileCap<T>::value : 0ull;
@@ -1082,10 +1095,10 @@ static void coo_to_compressed_device(Context *ctx, Scratch &sc, uint64_t nseg, u
     OSP_HIP(hipMemsetAsync(flags, 0, sizeof(uint32_t), s));
     // stable LSD: by inner index first, then by segment
     device_sort_rows<RsStoreEpilogue>(inner, nnz, std::max(1, bits_for(ninner)), ka, pa, kb, pb, hist, hist_tmp,
-                                      RsStoreEpilogue{k1, perm1}, s);
+                                      RsStoreEpilogue{k1, perm1}, s, ctx->rank_atomic);
     ingest_gather_u32_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(seg, perm1, nnz, k2);
     device_sort_rows<RsStoreEpilogue>(k2, nnz, std::max(1, bits_for(nseg)), ka, pa, kb, pb, hist, hist_tmp,
-                                      RsStoreEpilogue{seg_sorted, perm2}, s, perm1);
+                                      RsStoreEpilogue{seg_sorted, perm2}, s, ctx->rank_atomic, perm1);
     ingest_finish_kernel<T><<<grid_for(nnz, 256), 256, 0, s>>>(seg_sorted, perm2, inner, vals, nnz, nseg, ninner, idx, ov, flags);
     ingest_ptr_kernel<<<grid_for(nseg + 1, 256), 256, 0, s>>>(seg_sorted, nnz, nseg, ptr);
     check_flags(d2h(flags, s), what);
@@ -1271,21 +1284,29 @@ static int context_create(int device, void *stream, bool own, osp_context_t *out
     c->cus = (uint32_t)prop.multiProcessorCount;
     if (own) { OSP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     else c->stream = (hipStream_t)stream;
-#if OSP_RANK_ATOMIC
     try {
-        Scratch sc(c);
-        uint32_t *bad = sc.get<uint32_t>(1);
-        OSP_HIP(hipMemsetAsync(bad, 0, sizeof(uint32_t), c->stream));
-        rank_order_selftest_kernel<<<64, 256, 0, c->stream>>>(bad);
-        if (d2h(bad, c->stream) != 0)
-            throw Error(OSP_ERR_HIP, "LDS atomics do not return their old values in lane order on this device: build with -DOSP_RANK_ATOMIC=0");
+        // Which stable rank this context uses.  The atomic one needs a property of LDS atomics that is not documented, so
+        // it is tested here on THIS device; when the test fails the context falls back to the ballot instantiations of the
+        // same kernels (slower -- merge +20 % -- and just as exact) instead of refusing to work.
+        const char *force = getenv("OSP_RANK");   // "ballot" | "atomic": debugging and tests/test_gpu_parity.py
+        if (force && strcmp(force, "ballot") == 0) c->rank_atomic = false;
+        else if (force && strcmp(force, "atomic") == 0) c->rank_atomic = true;
+        if (c->rank_atomic) {
+            Scratch sc(c);
+            uint32_t *bad = sc.get<uint32_t>(1);
+            OSP_HIP(hipMemsetAsync(bad, 0, sizeof(uint32_t), c->stream));
+            rank_order_selftest_kernel<<<64, 256, 0, c->stream>>>(bad);
+            if (d2h(bad, c->stream) != 0) {
+                c->rank_atomic = false;
+                if (getenv("OSP_VERBOSE")) fprintf(stderr, "[osp] LDS atomics do not return old values in lane order on this device: using ballot ranks\n");
+            }
+        }
     } catch (...) {
         c->trim();
         if (c->own_stream) (void)hipStreamDestroy(c->stream);
         delete c;
         throw;
     }
-#endif
     *out = (osp_context_t)c;
     return OSP_OK;
     OSP_GUARD_END

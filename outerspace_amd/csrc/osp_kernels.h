@@ -710,7 +710,9 @@ constexpr int merge_waves_per_simd() {
     const int w = merge_wgs_per_cu<T, NT, CAP, MAXWG, ABL>() * NT / 256;
     return w > 8 ? 8 : (w < 1 ? 1 : w);
 }
-template <class T, int NT, int ABL = 0, int CAP = TileCap<T>::value, int MAXWG = kMergeMaxWgs>
+// RA: stable ranks from the return order of one LDS atomic (true) or from ballot matching (false); a context whose
+// self-test of that order fails runs the ballot instantiations (osp_api.hip, Context::rank_atomic).
+template <class T, int NT, int ABL = 0, int CAP = TileCap<T>::value, int MAXWG = kMergeMaxWgs, bool RA = (OSP_RANK_ATOMIC != 0)>
 __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>())) void merge_tiles_kernel(
     const TileDesc *__restrict__ desc, uint32_t ntiles, const MergeLevels<T> lvl, int colbits, uint64_t *tile_status,
     uint32_t *ticket, const uint64_t *__restrict__ out_base_p, uint32_t *__restrict__ c_col, T *__restrict__ c_val,
@@ -822,7 +824,21 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
         constexpr bool INPLACE = (ABL & 32) != 0;
         const bool early = nbits > 0 && keybits < 32 && !(ABL & 2) && !(ABL & 8) && !INPLACE;
         if (early) {
-            for (uint32_t i = tid; i < HS; i += NT) htab[i] = 0xffffffffu;
+            if constexpr (ABL & 256) {
+                for (uint32_t i = tid; i < HS; i += NT) htab[i] = 0xffffffffu;
+            } else {
+                // 16 bytes per lane and store: a quarter of the LDS store instructions (the table starts 8-byte aligned
+                // behind key0, so the first and last words are written singly)
+                static_assert(HS % 4 == 0 && (kTileCap * 4) % 8 == 0, "hash table: whole 16-byte groups behind an 8-byte aligned start");
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                constexpr uint32_t lead = ((kTileCap * 4) % 16) / 4;          // words up to the first 16-byte boundary
+                constexpr uint32_t nvec = (HS - lead) / 4, tail = (HS - lead) % 4;
+                u32x4 *hv = reinterpret_cast<u32x4 *>(htab + lead);
+                const u32x4 ones = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+                for (uint32_t i = tid; i < nvec; i += NT) hv[i] = ones;
+                if (tid < lead) htab[tid] = 0xffffffffu;
+                if (tid < tail) htab[lead + nvec * 4 + tid] = 0xffffffffu;
+            }
             if (tid == 0) sm.hcount = 0;
         }
         if (tid <= nr) sm.rowo[tid] = (uint32_t)(ro - base - s);
@@ -960,7 +976,14 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
         for (int pass = 0, shift = 0; pass < npass; pass++, shift += pbits) {
             uint32_t *ksrc = sm.key(cur), *kdst = sm.key(cur ^ 1);
             uint16_t *psrc = sm.pos(cur), *pdst = sm.pos(cur ^ 1);
-            for (int dd = lane; dd < ndig; dd += kWave) sm.cnt[w][dd] = 0;
+            if constexpr (ABL & 128) {
+                for (int dd = lane; dd < ndig; dd += kWave) sm.cnt[w][dd] = 0;
+            } else {
+                // four 16-bit counters per lane and store (the rows are 8-byte aligned; a short digit range zeroes a few
+                // counters beyond it, which nobody reads)
+                uint64_t *c64 = reinterpret_cast<uint64_t *>(sm.cnt[w]);
+                for (int dd = lane; dd < (ndig + 3) / 4; dd += kWave) c64[dd] = 0ull;
+            }
             // (a) rank inside the wave's span; keys and ranks stay in registers for (c)
             uint32_t kreg[ITERS], rreg[ITERS];
             auto rank_span = [&](auto bits_tag) {
@@ -981,7 +1004,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                     }
                 }
             };
-#if OSP_RANK_ATOMIC
+            if constexpr (RA) {
             // Rank by LDS atomic: one ds_add_rtn on the wave's packed 16-bit counter returns "entries of this digit so far",
             // and lanes that hit the same counter in one instruction get their old values in ascending lane order -- which
             // is exactly the stable rank.  (The order is not documented; tools/test_lds_atomic_order checked 1.8e10 ranks on
@@ -1001,15 +1024,15 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                 }
                 (void)rank_span;
             }
-#else
+            } else {
             // the widest digits only when they save a pass (20 key bits in two passes); else one ballot less
             if (pbits > kDigitBits - 1) rank_span(std::integral_constant<int, kDigitBits>{});
             else rank_span(std::integral_constant<int, kDigitBits - 1>{});
-#endif
+            }
             __syncthreads();
             OSP_PROF_MARK(3);
             // (b) exclusive scan over (digit major, wave minor); a thread owns dpt consecutive digits
-            {
+            if constexpr ((ABL & 128) != 0 || DPT != 4) {
                 const int dpt = ndig > NT ? ndig / NT : 1;  // ndig and NT are powers of two
                 uint32_t c[DPT][NW], ssum = 0;
 #pragma unroll
@@ -1028,6 +1051,35 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
 #pragma unroll
                         for (int ww = 0; ww < NW; ww++) { sm.cnt[ww][dg] = (uint16_t)ex; ex += c[q][ww]; }
                     }
+                }
+            } else {
+                // A thread owns FOUR consecutive digits whatever the digit range (threads beyond it idle): the four 16-bit
+                // counters of one wave are one aligned 8-byte word -- one LDS load and one LDS store per wave row instead of
+                // four each.
+                const bool on = (int)tid * 4 < ndig;
+                uint64_t pk[NW];
+                uint32_t ssum = 0;
+#pragma unroll
+                for (int ww = 0; ww < NW; ww++) {
+                    pk[ww] = on ? reinterpret_cast<const uint64_t *>(sm.cnt[ww])[tid] : 0ull;
+                    // sum of the four 16-bit fields (each < 2^16, the sum < 2^18)
+                    ssum += (uint32_t)(pk[ww] & 0xffffu) + (uint32_t)((pk[ww] >> 16) & 0xffffu) + (uint32_t)((pk[ww] >> 32) & 0xffffu) +
+                            (uint32_t)(pk[ww] >> 48);
+                }
+                uint32_t total;
+                uint32_t ex = block_excl_scan<uint32_t, NT>(ssum, sm.scratch, &total);
+                if (on) {
+                    // digit-major, wave-minor exclusive offsets
+                    uint32_t o[4][NW];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+#pragma unroll
+                        for (int ww = 0; ww < NW; ww++) { o[q][ww] = ex; ex += (uint32_t)(pk[ww] >> (16 * q)) & 0xffffu; }
+                    }
+#pragma unroll
+                    for (int ww = 0; ww < NW; ww++)
+                        reinterpret_cast<uint64_t *>(sm.cnt[ww])[tid] = (uint64_t)(o[0][ww] & 0xffffu) | ((uint64_t)(o[1][ww] & 0xffffu) << 16) |
+                                                                        ((uint64_t)(o[2][ww] & 0xffffu) << 32) | ((uint64_t)(o[3][ww] & 0xffffu) << 48);
                 }
             }
             __syncthreads();

@@ -10,7 +10,9 @@
 
 // Stable radix ranks by LDS atomic (1) or by ballot matching (0).  One ds_add_rtn instruction hands its old values to
 // the lanes that hit the same counter in ascending lane order -- undocumented, so tools/test_lds_atomic_order checks it
-// (1.8e10 ranks on gfx950, none out of order) and every parity test compares values bit for bit.
+// (1.8e10 ranks on gfx950, none out of order), every parity test compares values bit for bit, and every context tests
+// it when it is created: BOTH variants of every ranking kernel are compiled (template parameter RA), and a context whose
+// self-test fails runs the ballot ones.  The macro only sets what a context prefers (0 = ballot always: `make ballot`).
 #ifndef OSP_RANK_ATOMIC
 #define OSP_RANK_ATOMIC 1
 #endif
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const K *keys, 
     hist[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-template <class K>
+template <class K, bool RA>
 __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(
     const K *keys_in, const uint32_t *vals_in, K *keys_out, uint32_t *vals_out, uint64_t n,
     int shift, const uint32_t *hist_scan, uint32_t nblocks) {
@@ -255,14 +257,14 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(
             val = vals_in[i];
         }
         const unsigned d = (unsigned)(key >> shift) & 255u;
-#if OSP_RANK_ATOMIC
-        unsigned rank = 0;  // stable rank by LDS atomic: old values come back in lane order (see merge_tiles_kernel)
-        if (valid) rank = atomicAdd(&cnt[w][d], 1u);
-#else
-        const uint64_t peers = wave_match8(d, valid);
-        const unsigned rank = __popcll(peers & lanemask_lt());
-        if (valid && rank == 0) cnt[w][d] = (uint32_t)__popcll(peers);
-#endif
+        unsigned rank = 0;
+        if constexpr (RA) {  // stable rank by LDS atomic: old values come back in lane order (see merge_tiles_kernel)
+            if (valid) rank = atomicAdd(&cnt[w][d], 1u);
+        } else {
+            const uint64_t peers = wave_match8(d, valid);
+            rank = __popcll(peers & lanemask_lt());
+            if (valid && rank == 0) cnt[w][d] = (uint32_t)__popcll(peers);
+        }
         __syncthreads();
         if (valid) {
             uint32_t off = base[d] + rank;
@@ -299,7 +301,7 @@ inline uint64_t sort_hist_entries(uint64_t n) { return sort_blocks(n) * kRadix +
 // index (0/1) of the buffer holding the sorted data.  n must be < 2^32.
 template <class K>
 inline int device_radix_sort_pairs(K *keys[2], uint32_t *vals[2], uint64_t n, int nbits,
-                                   uint32_t *hist, uint32_t *scan_scratch, hipStream_t stream) {
+                                   uint32_t *hist, uint32_t *scan_scratch, hipStream_t stream, bool rank_atomic) {
     int cur = 0;
     if (n == 0) return cur;
     const uint32_t nblocks = (uint32_t)sort_blocks(n);
@@ -308,8 +310,12 @@ inline int device_radix_sort_pairs(K *keys[2], uint32_t *vals[2], uint64_t n, in
         // in-place exclusive scan of the digit-major histogram (reads precede writes per tile)
         device_exclusive_scan<LoadU32, uint32_t>(LoadU32{hist}, (uint64_t)nblocks * kRadix, hist,
                                                  scan_scratch, stream);
-        sort_scatter_kernel<K><<<nblocks, kSortThreads, 0, stream>>>(
-            keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist, nblocks);
+        if (rank_atomic)
+            sort_scatter_kernel<K, true><<<nblocks, kSortThreads, 0, stream>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift,
+                                                                                hist, nblocks);
+        else
+            sort_scatter_kernel<K, false><<<nblocks, kSortThreads, 0, stream>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift,
+                                                                                 hist, nblocks);
         cur ^= 1;
     }
     return cur;

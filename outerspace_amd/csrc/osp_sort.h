@@ -44,7 +44,7 @@ struct RsNoEpilogue {
     __device__ void operator()(uint64_t, uint32_t, uint32_t) const {}
 };
 
-template <bool FIRST, bool LAST, class Epi>
+template <bool FIRST, bool LAST, bool RA, class Epi>
 __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint32_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, uint64_t n, int shift, const uint32_t *__restrict__ hist_scan, uint32_t nblocks,
@@ -79,19 +79,19 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
         const bool valid = i < n;
         const unsigned d = (kreg[it] >> shift) & 255u;
         rreg[it] = 0;
-#if OSP_RANK_ATOMIC
-        // stable rank by LDS atomic on the wave's packed 16-bit counter (see merge_tiles_kernel)
-        const unsigned half = 16u * (d & 1u);
-        if (valid) rreg[it] = (atomicAdd(&reinterpret_cast<uint32_t *>(cnt[w])[d >> 1], 1u << half) >> half) & 0xffffu;
-#else
-        const uint64_t peers = wave_match8(d, valid);
-        const unsigned rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
-        if (valid) {
-            const uint32_t c = cnt[w][d];
-            rreg[it] = c + rk;
-            if (rk == 0) cnt[w][d] = (uint16_t)(c + (uint32_t)__popcll(peers));
+        if constexpr (RA) {
+            // stable rank by LDS atomic on the wave's packed 16-bit counter (see merge_tiles_kernel)
+            const unsigned half = 16u * (d & 1u);
+            if (valid) rreg[it] = (atomicAdd(&reinterpret_cast<uint32_t *>(cnt[w])[d >> 1], 1u << half) >> half) & 0xffffu;
+        } else {
+            const uint64_t peers = wave_match8(d, valid);
+            const unsigned rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+            if (valid) {
+                const uint32_t c = cnt[w][d];
+                rreg[it] = c + rk;
+                if (rk == 0) cnt[w][d] = (uint16_t)(c + (uint32_t)__popcll(peers));
+            }
         }
-#endif
     }
     __syncthreads();
     {   // digit totals -> LDS start of every digit, and per-wave offsets inside the digit
@@ -142,10 +142,10 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
 // Sort (keys_raw[i], i) by the low `nbits` bits of the key.  Buffers a and b are (key, payload) pairs
 // of n entries each; the last pass calls epi(sorted position, key, payload) instead of storing.
 // hist needs rs_hist_entries(n) u32, scan_scratch scan_scratch_entries(rs_hist_entries(n)).
-template <class Epi>
-inline void device_sort_rows(const uint32_t *keys_raw, uint64_t n, int nbits, uint32_t *ka, uint32_t *pa, uint32_t *kb,
-                             uint32_t *pb, uint32_t *hist, uint32_t *scan_scratch, Epi epi, hipStream_t stream,
-                             const uint32_t *vals_raw = nullptr /* payload of keys_raw[i]; default: i itself */) {
+template <bool RA, class Epi>
+inline void device_sort_rows_ra(const uint32_t *keys_raw, uint64_t n, int nbits, uint32_t *ka, uint32_t *pa, uint32_t *kb,
+                                uint32_t *pb, uint32_t *hist, uint32_t *scan_scratch, Epi epi, hipStream_t stream,
+                                const uint32_t *vals_raw) {
     if (n == 0) return;
     const uint32_t nb = rs_blocks(n);
     const int npass = std::max(1, (nbits + 7) / 8);
@@ -157,13 +157,22 @@ inline void device_sort_rows(const uint32_t *keys_raw, uint64_t n, int nbits, ui
         if (first) rs_hist_kernel<true><<<nb, kRsThreads, 0, stream>>>(kin, n, shift, hist, nb);
         else rs_hist_kernel<false><<<nb, kRsThreads, 0, stream>>>(kin, n, shift, hist, nb);
         device_exclusive_scan<LoadU32, uint32_t>(LoadU32{hist}, (uint64_t)nb * kRadix, hist, scan_scratch, stream);
-        if (first && last) rs_scatter_kernel<true, true, Epi><<<nb, kRsThreads, 0, stream>>>(kin, pin, kout, pout, n, shift, hist, nb, epi);
-        else if (first) rs_scatter_kernel<true, false, Epi><<<nb, kRsThreads, 0, stream>>>(kin, pin, kout, pout, n, shift, hist, nb, epi);
-        else if (last) rs_scatter_kernel<false, true, Epi><<<nb, kRsThreads, 0, stream>>>(kin, pin, kout, pout, n, shift, hist, nb, epi);
-        else rs_scatter_kernel<false, false, Epi><<<nb, kRsThreads, 0, stream>>>(kin, pin, kout, pout, n, shift, hist, nb, epi);
+        if (first && last) rs_scatter_kernel<true, true, RA, Epi><<<nb, kRsThreads, 0, stream>>>(kin, pin, kout, pout, n, shift, hist, nb, epi);
+        else if (first) rs_scatter_kernel<true, false, RA, Epi><<<nb, kRsThreads, 0, stream>>>(kin, pin, kout, pout, n, shift, hist, nb, epi);
+        else if (last) rs_scatter_kernel<false, true, RA, Epi><<<nb, kRsThreads, 0, stream>>>(kin, pin, kout, pout, n, shift, hist, nb, epi);
+        else rs_scatter_kernel<false, false, RA, Epi><<<nb, kRsThreads, 0, stream>>>(kin, pin, kout, pout, n, shift, hist, nb, epi);
         kin = kout; pin = pout;
         if (kout == ka) { kout = kb; pout = pb; } else { kout = ka; pout = pa; }
     }
+}
+
+// rank_atomic: which instantiation of the stable rank runs (Context::rank_atomic)
+template <class Epi>
+inline void device_sort_rows(const uint32_t *keys_raw, uint64_t n, int nbits, uint32_t *ka, uint32_t *pa, uint32_t *kb,
+                             uint32_t *pb, uint32_t *hist, uint32_t *scan_scratch, Epi epi, hipStream_t stream, bool rank_atomic,
+                             const uint32_t *vals_raw = nullptr /* payload of keys_raw[i]; default: i itself */) {
+    if (rank_atomic) device_sort_rows_ra<true, Epi>(keys_raw, n, nbits, ka, pa, kb, pb, hist, scan_scratch, epi, stream, vals_raw);
+    else device_sort_rows_ra<false, Epi>(keys_raw, n, nbits, ka, pa, kb, pb, hist, scan_scratch, epi, stream, vals_raw);
 }
 
 // plain epilogue: store the sorted pairs

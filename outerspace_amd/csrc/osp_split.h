@@ -104,7 +104,7 @@ __device__ __forceinline__ void wave_match_bits(unsigned digit, int bits, bool v
 }
 
 // stable scatter of one stretch into the row's segments; goffs = exclusive scan of ghist
-template <class T>
+template <class T, bool RA>
 __global__ __launch_bounds__(kSplitThreads) void split_scatter_kernel(
     const uint32_t *rows, uint32_t nheavy, const uint64_t *blkbase, const uint64_t *hbase, const uint8_t *hbits,
     const uint32_t *nstretch, const uint64_t *row_off, uint64_t base, int colbits, const Part<T> *stage,
@@ -143,19 +143,19 @@ __global__ __launch_bounds__(kSplitThreads) void split_scatter_kernel(
             const bool valid = i < se;
             const unsigned d = rec[it].col() >> sh;
             rk[it] = 0;
-#if OSP_RANK_ATOMIC
-            // stable rank by LDS atomic on the wave's packed 16-bit counter (see merge_tiles_kernel)
-            const unsigned half = 16u * (d & 1u);
-            if (valid) rk[it] = (atomicAdd(&reinterpret_cast<uint32_t *>(cnt[w])[d >> 1], 1u << half) >> half) & 0xffffu;
-#else
-            unsigned r, c;
-            wave_match_bits(d, (int)j.b, valid, r, c);
-            if (valid) {
-                const uint32_t cur = cnt[w][d];
-                rk[it] = cur + r;
-                if (r == 0) cnt[w][d] = (uint16_t)(cur + c);
+            if constexpr (RA) {
+                // stable rank by LDS atomic on the wave's packed 16-bit counter (see merge_tiles_kernel)
+                const unsigned half = 16u * (d & 1u);
+                if (valid) rk[it] = (atomicAdd(&reinterpret_cast<uint32_t *>(cnt[w])[d >> 1], 1u << half) >> half) & 0xffffu;
+            } else {
+                unsigned r, c;
+                wave_match_bits(d, (int)j.b, valid, r, c);
+                if (valid) {
+                    const uint32_t cur = cnt[w][d];
+                    rk[it] = cur + r;
+                    if (r == 0) cnt[w][d] = (uint16_t)(cur + c);
+                }
             }
-#endif
         }
         __syncthreads();
         // per segment: the waves' exclusive offsets, stored RELATIVE TO THE END of the round's entries of the segment
@@ -204,7 +204,7 @@ __global__ void split_vrows_kernel(uint32_t nheavy, const uint64_t *vbase, const
 
 // One workgroup splits one long row of at most kSplitRowMax entries: histogram over its segments, scan, stable
 // scatter -- the row is read twice, the second time from L2.  No global histogram, no device-wide scan.
-template <class T>
+template <class T, bool RA>
 __global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
     const uint32_t *rows, uint32_t nheavy, const uint8_t *hbits, const uint32_t *nstretch, const uint64_t *vbase,
     const uint64_t *hoff, const uint64_t *row_off, uint64_t base, int colbits, const Part<T> *stage, Part<T> *qstage,
@@ -255,18 +255,18 @@ __global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
             const bool valid = i < se;
             const unsigned d = rec[it].col() >> sh;
             rk[it] = 0;
-#if OSP_RANK_ATOMIC
-            const unsigned half = 16u * (d & 1u);
-            if (valid) rk[it] = (atomicAdd(&reinterpret_cast<uint32_t *>(cnt[w])[d >> 1], 1u << half) >> half) & 0xffffu;
-#else
-            unsigned r, c;
-            wave_match_bits(d, (int)b, valid, r, c);
-            if (valid) {
-                const uint32_t cur = cnt[w][d];
-                rk[it] = cur + r;
-                if (r == 0) cnt[w][d] = (uint16_t)(cur + c);
+            if constexpr (RA) {
+                const unsigned half = 16u * (d & 1u);
+                if (valid) rk[it] = (atomicAdd(&reinterpret_cast<uint32_t *>(cnt[w])[d >> 1], 1u << half) >> half) & 0xffffu;
+            } else {
+                unsigned r, c;
+                wave_match_bits(d, (int)b, valid, r, c);
+                if (valid) {
+                    const uint32_t cur = cnt[w][d];
+                    rk[it] = cur + r;
+                    if (r == 0) cnt[w][d] = (uint16_t)(cur + c);
+                }
             }
-#endif
         }
         __syncthreads();
         // per segment: exclusive offsets of the waves inside this stretch; cnt[NW] keeps the stretch's total

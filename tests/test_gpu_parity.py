@@ -596,33 +596,48 @@ def test_rmat22_full_size_properties_and_slab_parity(ctx, port):
       * size-independent properties of the WHOLE result, checked on the device: rowptr monotone and ending at nnz,
         columns strictly ascending inside every row, row sums C*1 = A*(B*1), total 1^T C 1 = (1^T A)(B 1);
       * linearity: the product of (2A) and B, streamed panel by panel, is exactly 2C with the same structure;
-      * parity proper on a k-slab: columns [0, k1) of A times rows [0, k1) of B (about 6e7 partial products, the
-        unit a k-shard computes) against the oracle, bit for bit."""
+      * parity proper on two k-slabs (the unit a k-shard computes), bit for bit against the oracle: the hub column k = 0
+        alone (9.9e7 partial products, no duplicates) and 77 k columns from the middle of the range (5e7 partial products)."""
+    import sys
+    import time
     import torch
     from outerspace_amd.distributed import _as_tensor
+    t_start = time.time()
+
+    def note(what):  # progress on the real stderr: a long test must not look hung
+        print(f"[rmat22 {time.time() - t_start:6.1f} s] {what}", file=sys.__stderr__, flush=True)
     dev = torch.device("cuda", 0)
     if "rmat22" not in _FULL:
         _FULL["rmat22"] = _bench_module().rmat_device(22, 16, gen.RMAT_PRESETS["mild"], 1, dev, torch.float64)
     n, csr, csc = _FULL["rmat22"]
     ptrs = [t.data_ptr() for t in (*csc, *csr)]
-    # ---- slab parity against the oracle ----
+    # ---- slab parity against the oracle: the hub column alone (k = 0: one outer product, no duplicate coordinates, the
+    # longest chunks there are) and a slab from the middle of the k range (tens of thousands of columns, many duplicates) ----
     w = (csc[0][1:] - csc[0][:-1]) * (csr[0][1:] - csr[0][:-1])
-    k1 = int(torch.searchsorted(torch.cumsum(w, 0), torch.tensor([60_000_000], device=dev))[0]) + 1
-    ea, eb = int(csc[0][k1]), int(csr[0][k1])
-    host = [csc[0][:k1 + 1].cpu().numpy(), csc[1][:ea].cpu().numpy().view(np.uint32), csc[2][:ea].cpu().numpy(),
-            csr[0][:k1 + 1].cpu().numpy(), csr[1][:eb].cpu().numpy().view(np.uint32), csr[2][:eb].cpu().numpy()]
-    want = port.spgemm(n, k1, n, *host)
-    res = ctx.spgemm_csc_csr_device(np.float64, n, n, n, ptrs, k_range=(0, k1))
-    assert res.info["partials"] == want["partials"] and res.nnz == len(want["colidx"])
-    rp, ci, va = res.device_ptrs()
-    assert torch.equal(_as_tensor(rp, n + 1, "<i8", dev, torch.int64), torch.from_numpy(want["rowptr"]).to(dev))
-    assert torch.equal(_as_tensor(ci, res.nnz, "<i4", dev, torch.int32), torch.from_numpy(want["colidx"].view(np.int32)).to(dev))
-    assert torch.equal(_as_tensor(va, res.nnz, "<f8", dev, torch.float64), torch.from_numpy(want["vals"]).to(dev))
-    res.close()
-    del want, host
+    cum = torch.cumsum(w, 0)
+    km = n // 3
+    k_hi = int(torch.searchsorted(cum, (cum[km - 1] + 50_000_000).reshape(1))[0]) + 1
+    for k0, k1 in ((0, 1), (km, k_hi)):
+        ea0, ea1, eb0, eb1 = int(csc[0][k0]), int(csc[0][k1]), int(csr[0][k0]), int(csr[0][k1])
+        host = [(csc[0][k0:k1 + 1] - ea0).cpu().numpy(), csc[1][ea0:ea1].cpu().numpy().view(np.uint32), csc[2][ea0:ea1].cpu().numpy(),
+                (csr[0][k0:k1 + 1] - eb0).cpu().numpy(), csr[1][eb0:eb1].cpu().numpy().view(np.uint32), csr[2][eb0:eb1].cpu().numpy()]
+        note(f"k-slab [{k0},{k1}): {int(w[k0:k1].sum())} partial products for the oracle")
+        want = port.spgemm(n, k1 - k0, n, *host)
+        note("oracle done")
+        res = ctx.spgemm_csc_csr_device(np.float64, n, n, n, ptrs, k_range=(k0, k1))
+        assert res.info["partials"] == want["partials"] == int(w[k0:k1].sum()) and res.nnz == len(want["colidx"])
+        rp, ci, va = res.device_ptrs()
+        assert torch.equal(_as_tensor(rp, n + 1, "<i8", dev, torch.int64), torch.from_numpy(want["rowptr"]).to(dev))
+        assert torch.equal(_as_tensor(ci, res.nnz, "<i4", dev, torch.int32), torch.from_numpy(want["colidx"].view(np.int32)).to(dev))
+        assert torch.equal(_as_tensor(va, res.nnz, "<f8", dev, torch.float64), torch.from_numpy(want["vals"]).to(dev))
+        res.close()
+        del want, host
+    del cum
     # ---- the whole product ----
+    note("slab parity ok; whole product")
     res = ctx.spgemm_csc_csr_device(np.float64, n, n, n, ptrs)
     nnz = res.nnz
+    note(f"whole product done: nnz {nnz}, {res.info['ms_total']:.0f} ms")
     assert res.info["partials"] == int(w.sum()) and nnz > 11_000_000_000
     rp, ci, va = res.device_ptrs()
     rowptr = _as_tensor(rp, n + 1, "<i8", dev, torch.int64)
@@ -634,22 +649,26 @@ def test_rmat22_full_size_properties_and_slab_parity(ctx, port):
     want_rowsum = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, csc[1].long(), csc[2] * torch.repeat_interleave(
         b1, csc[0][1:] - csc[0][:-1]))                                                                       # A * (B * 1)
     got_rowsum = torch.zeros(n, dtype=torch.float64, device=dev)
-    CH = 1 << 28
-    for lo in range(0, nnz, CH):
-        hi = min(lo + CH, nnz)
-        pos = torch.arange(lo, hi, device=dev)
-        rows = torch.searchsorted(rowptr, pos, right=True) - 1
-        got_rowsum.index_add_(0, rows, vals[lo:hi])
-        # strictly ascending columns inside a row: col[i] > col[i-1] unless i starts a row
-        if hi - lo > 1:
-            c = colidx[lo:hi].long() & 0xffffffff
-            same_row = rows[1:] == rows[:-1]
-            assert bool((c[1:][same_row] > c[:-1][same_row]).all()), "columns must ascend strictly inside every row"
-        if lo:  # the pair across the chunk boundary
-            r_prev = int(torch.searchsorted(rowptr, torch.tensor([lo - 1], device=dev), right=True)[0]) - 1
-            if r_prev == int(rows[0]):
-                assert int(colidx[lo]) & 0xffffffff > int(colidx[lo - 1]) & 0xffffffff
-        del pos, rows
+    ctx.trim()   # the checks below allocate through torch: give it the staging memory the product has released
+    # walk the result in blocks of whole rows holding about 2^27 entries: per-row sums by segment reduction (an index_add_
+    # of sorted indices would serialise on one address per row), column order by comparing neighbours
+    CH = 1 << 27
+    cuts = torch.searchsorted(rowptr, torch.arange(0, nnz + CH, CH, device=dev).clamp_(max=nnz)).tolist()
+    cuts = sorted(set([0] + [min(int(x), n) for x in cuts] + [n]))
+    for bi, (ra, rb) in enumerate(zip(cuts[:-1], cuts[1:])):
+        lo, hi = int(rowptr[ra]), int(rowptr[rb])
+        if hi == lo:
+            continue
+        lengths = rowptr[ra + 1:rb + 1] - rowptr[ra:rb]
+        got_rowsum[ra:rb] = torch.segment_reduce(vals[lo:hi], "sum", lengths=lengths, unsafe=True)
+        rows = torch.repeat_interleave(torch.arange(ra, rb, device=dev, dtype=torch.int32), lengths)
+        c = colidx[lo:hi]   # columns < 2^22 here: int32 compares as unsigned
+        bad = (c[1:] <= c[:-1]) & (rows[1:] == rows[:-1])
+        assert not bool(bad.any()), "columns must ascend strictly inside every row"
+        del rows, c, bad, lengths
+        if bi % 16 == 0:
+            note(f"walked {hi} of {nnz} entries")
+    note("structure and row sums walked")
     assert torch.allclose(got_rowsum, want_rowsum, rtol=1e-9, atol=0)
     assert abs(float(got_rowsum.sum()) - float(want_rowsum.sum())) <= 1e-9 * float(want_rowsum.sum())
     del got_rowsum, want_rowsum, b1
@@ -663,6 +682,7 @@ def test_rmat22_full_size_properties_and_slab_parity(ctx, port):
         assert p["nnz"] == int(rowptr[p["row_end"]]) - lo
         prp = _as_tensor(p["rowptr"], nr + 1, "<i8", dev, torch.int64)
         assert torch.equal(prp, rowptr[p["row_begin"]:p["row_end"] + 1] - lo)
+        note(f"panel {p['index'] + 1} of {p['count']}")
         for s0 in range(0, p["nnz"], CH):
             s1 = min(s0 + CH, p["nnz"])
             assert torch.equal(_as_tensor(p["colidx"] + 4 * s0, s1 - s0, "<i4", dev, torch.int32), colidx[lo + s0:lo + s1])
@@ -670,6 +690,7 @@ def test_rmat22_full_size_properties_and_slab_parity(ctx, port):
         seen["rows"] += nr
         seen["nnz"] += p["nnz"]
     info = ctx.spgemm_csc_csr_panels(np.float64, n, n, n, [csc[0].data_ptr(), csc[1].data_ptr(), a2.data_ptr(), *ptrs[3:]], on_panel)
+    note("streamed (2A)*B compared")
     assert seen["rows"] == n and seen["nnz"] == nnz == info["nnz_c"] and info["panels"] >= 2
     res.close()
     del rowptr, colidx, vals, a2

@@ -1,6 +1,6 @@
 // tools/bench_merge.hip -- A/B timing of merge_tiles_kernel variants in ONE process (interleaved rounds).
 // Synthetic staging buffer: rows of `rowlen` partial products with random columns in [0, 2^22).
-// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I outerspace_amd/csrc tools/bench_merge.hip -o tools/bench_merge
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I outerspace_amd/csrc -I tools tools/bench_merge.hip -o tools/bench_merge
 #define OSP_MERGE_PROF 1
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -33,6 +33,18 @@ __global__ void fill_sorted_kernel(uint32_t *pcol, uint64_t n, uint32_t clen) {
     uint64_t x = c * 0x9E3779B97F4A7C15ull; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
     const uint32_t stride = (1u << 22) / clen;
     pcol[i] = (uint32_t)(x % stride) + (uint32_t)j * stride;
+}
+// level-1 look-alike (L1BITS=b): the rows of a tile are consecutive column ranges of width 2^b / rpt, key = col - 0
+__global__ void fill_l1_kernel(uint32_t *pcol, uint64_t n, uint32_t rowlen, uint32_t rpt, uint32_t width) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t x = i * 0x9E3779B97F4A7C15ull; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    const uint32_t r = (uint32_t)((i / rowlen) % rpt);
+    pcol[i] = r * width + (uint32_t)(x % width);
+}
+__global__ void desc_l1_kernel(TileDesc *desc, uint32_t ntiles, uint32_t kbits) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ntiles) { desc[i].kbits = kbits; desc[i].cbase = 0; }
 }
 __global__ void chunks_kernel(uint64_t *chunk_start, uint64_t nchunks, uint32_t clen) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,6 +129,8 @@ int main(int argc, char **argv) {
     const uint32_t clen = argc > 4 ? atoi(argv[4]) : 16;
     fill_kernel<<<(unsigned)((P + 255) / 256), 256>>>(pcol, pval, P);
     fill_sorted_kernel<<<(unsigned)((P + 255) / 256), 256>>>(pcol, P, clen);
+    const uint32_t l1bits = getenv("L1BITS") ? atoi(getenv("L1BITS")) : 0;
+    if (l1bits) fill_l1_kernel<<<(unsigned)((P + 255) / 256), 256>>>(pcol, P, rowlen, rpt, (1u << l1bits) / rpt);
     CK(hipMalloc(&g_arow, (M + 1) * 4)); CK(hipMalloc(&g_chunk_start, (P / clen + 2) * 8));
     chunks_kernel<<<(unsigned)((P / clen + 256) / 256), 256>>>(g_chunk_start, P / clen, clen);
     arow_kernel<<<(unsigned)((M + 256) / 256), 256>>>(g_arow, M, rowlen / clen);
@@ -126,6 +140,7 @@ int main(int argc, char **argv) {
     pack_kernel<<<(unsigned)((P + 255) / 256), 256>>>(pcol, pval, P, g_stage);
     CK(hipMalloc(&g_desc, (uint64_t)ntiles * sizeof(TileDesc)));
     tile_desc_kernel<1 << 20><<<(ntiles + 255) / 256, 256>>>(tile_rows, ntiles, M, row_off, 0, 0u, nullptr, nullptr, 0u, nullptr, 22, nullptr, nullptr, g_desc);
+    if (l1bits) desc_l1_kernel<<<(ntiles + 255) / 256, 256>>>(g_desc, ntiles, l1bits);
     if (getenv("GRID")) g_grid = atoi(getenv("GRID"));
     CK(hipDeviceSynchronize());
     printf("P=%llu partials, %u tiles of %u rows x %u (%u per tile), algorithmic bytes %.2f GB\n", (unsigned long long)P, ntiles, rpt,
@@ -136,6 +151,8 @@ int main(int argc, char **argv) {
         {"radix NT256 cap1536 full", 1536, run<256, 0, 1536>}, {"radix NT256 cap1536 nosort", 1536, run<256, 1, 1536>},
         {"radix NT256 cap1536 nolb", 1536, run<256, 2, 1536>}, {"radix NT256 cap1536 nosort+nolb", 1536, run<256, 3, 1536>},
         {"radix NT256 cap1536 latecount", 1536, run<256, 8, 1536>},
+        {"radix NT256 cap1536 b16 counters", 1536, run<256, 128, 1536>}, {"radix NT256 cap1536 b32 hash init", 1536, run<256, 256, 1536>},
+        {"radix NT256 cap1536 old lds ops", 1536, run<256, 128 + 256, 1536>},
         {"radix NT256 cap1536 4wg", 1536, run<256, 0, 1536, 4>}, {"radix NT256 cap1792 full", 1792, run<256, 0, 1792>},
         {"radix NT256 cap2048 full", 2048, run<256, 0, 2048>}, {"radix NT256 cap1280 6wg", 1280, run<256, 0, 1280, 6>},
         {"radix NT512 cap3072 full", 3072, run<512, 0, 3072>},
