@@ -525,6 +525,14 @@ __global__ __launch_bounds__(256) void rank_order_selftest_kernel(uint32_t *bad)
     if (nbad) atomicAdd(bad, nbad);
 }
 
+// (Tickets: the persistent workgroups of merge_tiles_kernel take their tiles from ONE counter word.  A word serves about 88
+// returning atomics per microsecond on MI355X whoever asks (/opt/skills/guides/MI355X_MICROARCH.md, price list, "dequeue"),
+// and the kernel hands out 68-76 tiles per microsecond: the counter is at ~80 % of what it can give, and with everything
+// but load, sort and store switched off tools/bench_merge runs at exactly that bound (2.19 ms for 174 763 tiles).  A
+// two-level dispenser -- eight group words holding chunks of 32 tickets claimed on demand from a global counter -- was
+// built and measured: correct for every grid size, and much SLOWER (4.0 against 2.36 ms): 160 workgroups per group drain
+// a chunk faster than its refill's two dependent atomics come back.  Interleaved per-group counters would lift the bound
+// but can deadlock when a whole group of workgroups is not resident; not done.)
 // Exclusive prefix of tile `t` by decoupled look-back (called by wave 0 of the block).
 // One round trip fetches kLookWin windows of 64 predecessors.  (Measured: wide windows lose -- the
 // extra polling traffic costs more than the walk saves -- so kLookWin = 1; what matters is that tiles
@@ -565,7 +573,7 @@ __device__ __forceinline__ uint64_t lookback_prefix(uint64_t *status, uint32_t t
             }
         }
         if (retry) { __builtin_amdgcn_s_sleep(1); continue; }  // keep what is already summed? no: re-read all
-        excl += wave_reduce_sum(part);
+        excl += wave_reduce_sum_u62(part);
         if (done) break;
         b -= (int64_t)kLookWin * kWave;
     }
@@ -688,7 +696,8 @@ __device__ unsigned long long osp_merge_prof[16];
 #endif
 
 // ABL: ablation switches for tools/bench_merge.hip only (1 = no sort, 2 = no look-back, 4 = no ticket,
-// 8 = entry count published after the sort instead of by hashing).
+// 8 = entry count published after the sort instead of by hashing, 128 / 256 = narrow LDS accesses for the digit counters /
+// the hash table).
 // Bit 32 is a real mode, not an ablation: IN-PLACE tiles -- every tile is one over-long segment that is reduced where
 // it lies (records written back over its own beginning, entry count to heavy_nnz); no offset chain, no look-back.
 // the library always instantiates ABL = 0.
@@ -957,17 +966,16 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
             }
         }
         if (early) {
-            const uint32_t wsum = wave_reduce_sum(fresh);
-            if (lane == 0 && wsum) atomicAdd(&sm.hcount, wsum);
-            __syncthreads();
-            OSP_PROF_MARK(1);
-            if (tid == 0) lookback_publish(tile_status, t, sm.hcount);
+            const uint32_t wsum = wave_incl_scan(fresh);  // DPP: no LDS round trips; lane 63 holds the wave's total
+            if (lane == kWave - 1 && wsum) atomicAdd(&sm.hcount, wsum);
         }
         // each wave ranks a contiguous span, so earlier waves = earlier positions (stable)
         const uint32_t per = (n + NW - 1) / NW;
         const uint32_t wbeg = min(w * per, n), wend = min(wbeg + per, n);
         int cur = 0;
-        __syncthreads();
+        __syncthreads();   // keys staged, hash count complete
+        OSP_PROF_MARK(1);
+        if (early && tid == 0) lookback_publish(tile_status, t, sm.hcount);
         OSP_PROF_MARK(2);
         const int npass = (nbits + kDigitBits - 1) / kDigitBits;
         const int pbits = npass ? (nbits + npass - 1) / npass : 0;  // balanced digit width (<= kDigitBits)
@@ -1043,7 +1051,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                     for (int ww = 0; ww < NW; ww++) { c[q][ww] = on ? sm.cnt[ww][dg] : 0u; ssum += c[q][ww]; }
                 }
                 uint32_t total;
-                uint32_t ex = block_excl_scan<uint32_t, NT>(ssum, sm.scratch, &total);
+                uint32_t ex = block_excl_scan<uint32_t, NT, false>(ssum, sm.scratch, &total)  /* the barrier after the counter update follows */;
 #pragma unroll
                 for (int q = 0; q < DPT; q++) {
                     const int dg = tid * dpt + q;
@@ -1067,7 +1075,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                             (uint32_t)(pk[ww] >> 48);
                 }
                 uint32_t total;
-                uint32_t ex = block_excl_scan<uint32_t, NT>(ssum, sm.scratch, &total);
+                uint32_t ex = block_excl_scan<uint32_t, NT, false>(ssum, sm.scratch, &total)  /* the barrier after the counter update follows */;
                 if (on) {
                     // digit-major, wave-minor exclusive offsets
                     uint32_t o[4][NW];
@@ -1140,7 +1148,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
             }
         }
         uint32_t total;
-        uint32_t ex = block_excl_scan<uint32_t, NT>(heads, sm.scratch, &total);
+        uint32_t ex = block_excl_scan<uint32_t, NT, false>(heads, sm.scratch, &total);  // (the next scan is barriers away)
         OSP_PROF_MARK(6);
         // the tile's unique count is known: wave 0 runs the look-back and then requests the next ticket;
         // the ticket's round trip overlaps the run sums below

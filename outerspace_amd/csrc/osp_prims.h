@@ -60,9 +60,22 @@ __device__ __forceinline__ T wave_reduce_sum(T v) {
     return __shfl(v, 0, kWave);
 }
 
+// Sum of a 64-bit value over the wave, for every lane, without the LDS crossbar: three DPP scans over 24-bit slices
+// (each slice's sum over 64 lanes fits 32 bits).  Values must be below 2^62.
+__device__ __forceinline__ uint64_t wave_reduce_sum_u62(uint64_t v) {
+    const uint32_t a = wave_incl_scan((uint32_t)(v & 0xffffffu));
+    const uint32_t b = wave_incl_scan((uint32_t)((v >> 24) & 0xffffffu));
+    const uint32_t c = wave_incl_scan((uint32_t)(v >> 48));
+    const uint64_t sa = (uint32_t)__builtin_amdgcn_readlane((int)a, 63), sb = (uint32_t)__builtin_amdgcn_readlane((int)b, 63),
+                   sc = (uint32_t)__builtin_amdgcn_readlane((int)c, 63);
+    return sa + (sb << 24) + (sc << 48);
+}
+
 // Exclusive scan across a block of NT threads (NT multiple of 64, <= 1024).  `scratch` holds
 // NT/64 entries of T.  Returns the exclusive prefix of `v`; *total gets the block sum.
-template <class T, int NT>
+// TAILSYNC = false leaves out the barrier that protects `scratch` against the caller's NEXT scan: for callers that pass
+// another barrier of their own before they scan again.
+template <class T, int NT, bool TAILSYNC = true>
 __device__ __forceinline__ T block_excl_scan(T v, T *scratch, T *total) {
     constexpr int NW = NT / kWave;
     const T incl = wave_incl_scan(v);
@@ -77,7 +90,7 @@ __device__ __forceinline__ T block_excl_scan(T v, T *scratch, T *total) {
         tot += tv;
     }
     *total = tot;
-    __syncthreads();  // scratch may be reused by the caller's next scan
+    if (TAILSYNC) __syncthreads();  // scratch may be reused by the caller's next scan
     return incl - v + off;
 }
 
