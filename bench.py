@@ -31,6 +31,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+_T0 = time.time()
+
+
+def note(what):
+    """progress on stderr (rank 0): a run of several minutes must not look hung, and a crash should say where it was"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.time() - _T0:6.1f} s] {what}", file=sys.stderr, flush=True)
 
 
 def parse():
@@ -221,6 +228,7 @@ def cpu_baseline(ctx, csc, csr, n, target_partials, np_dtype, ptrs):
                      f"({P / secs / 1e6:.2f} M partials/s); host has {os.cpu_count()} cores, the reference is single-threaded",
            "partials_per_s": P / secs, "seconds": secs}
     # ---- the GPU on the same slab ----
+    note(f"reference done on k-slab [0,{k1}): {P} partial products in {secs:.1f} s; the same slab on the GPU")
     res = ctx.spgemm_csc_csr_device(np_dtype, n, n, n, ptrs, validate=False, k_range=(0, k1))
     tol = 1e-6 if np.dtype(np_dtype) == np.float64 else 1e-5
     par = {"status": "ok", "k_range": [0, k1], "partials": int(res.info["partials"]), "nnz": int(res.nnz), "against": kind,
@@ -338,6 +346,7 @@ def check_sum(got, want, dtype, what):
 def extra_workload(ctx, name, n, csr, csc, args, np_dtype, tdtype, device, E, stream, steps=3):
     """One secondary workload, measured the same way as the headline (fewer steps) and checked the same way."""
     import torch
+    torch.cuda.synchronize()   # the operands come from torch kernels on ANOTHER stream than the library's: they must be complete
     step, _ = make_step(ctx, n, csr, csc, np_dtype, tdtype, device, 0, stream)
     dt, infos = timed(step, steps, 1, torch.cuda.synchronize)
     info = infos[-1]
@@ -404,6 +413,7 @@ def main():
         workload_name = (f"R-MAT scale-{args.scale} edge-factor-{args.edge_factor} (a,b,c,d)={abcd} seed {args.seed}, "
                          f"duplicates removed, self-product C=A*A, CSC x CSR -> CSR")
     nnz_a = int(csr[0][-1])
+    note(f"operands on the device: n = {n}, nnz = {nnz_a}")
     want_sum = expected_value_sum(n, csr, csc, device)
     torch.cuda.synchronize()
     ctx = S.Context(dev_index)
@@ -423,7 +433,9 @@ def main():
         step, ptrs = make_step(ctx, n, csr, csc, np_dtype, tdtype, device, args.partial_capacity, args.stream_output)
         dt, infos = timed(step, args.steps, args.warmup, torch.cuda.synchronize)
         info = infos[-1]
+        note(f"{args.steps} timed steps: {dt / args.steps * 1e3:.1f} ms per step")
         chk = check_sum(step(checksum=True)["val_sum_global"], want_sum, args.dtype, "single GPU")
+        note("whole-result check passed")
         nnz_c, P = info["nnz_c"], info["partials"]
         ms_step = dt / args.steps * 1e3
         roof = kernel_roofline(infos, n, E)
@@ -449,6 +461,7 @@ def main():
         status = 0
         if args.cpu_baseline:
             out["cpu_baseline"], out["slab_parity"] = cpu_baseline(ctx, csc, csr, n, args.cpu_partials, np_dtype, ptrs)
+            note(f"CPU baseline {out['cpu_baseline']['value'] / 1e6:.1f} M nnz/s; slab parity: {out['slab_parity']['status']}")
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             if out["slab_parity"]["status"] != "ok":
                 status = 3
@@ -457,6 +470,7 @@ def main():
         from outerspace_amd import cost_model
         torch.cuda.synchronize()
         pred = cost_model.analytical(csc[0], csc[1], csr[0], value_size=np.dtype(np_dtype).itemsize)
+        note("cost model evaluated")
         pred["note"] = ("OuterSPACE analytical model restated from the reference (not a measurement): cycles of the "
                         "simulated accelerator, 64-B-aligned DRAM bytes per task")
         out["cost_model"] = pred
@@ -478,6 +492,7 @@ def main():
                     ("rmat20_g500_streamed", lambda: rmat_device(20, 16, gen.RMAT_PRESETS["g500"], args.seed, device, tdtype), True),
                     ("rmat22_uniform", lambda: rmat_device(22, 16, gen.RMAT_PRESETS["uniform"], args.seed, device, tdtype), False),
                     ("webgoogle_shape", lambda: webgoogle_device(args.seed, device, tdtype), False)):
+                note(f"extra workload {name}")
                 n2, csr2, csc2 = make()
                 extras[name] = extra_workload(ctx, name, n2, csr2, csc2, args, np_dtype, tdtype, device, E, stream,
                                               steps=5 if name == "webgoogle_shape" else 3)
@@ -499,6 +514,7 @@ def main():
             k_bounds = D.plan_k_shards(csc[0], csr[0], world)
             # this rank's operands: ONLY its columns of A and rows of B
             slab = D.slice_k_slab(csc, csr, k_bounds[rank], k_bounds[rank + 1])
+            torch.cuda.synchronize()   # (sliced by torch kernels; the library works on a stream of its own)
 
             def step(checksum=False):
                 return D.spgemm_k_sharded(ctx, np_dtype, n, n, slab, dist, rank, world, partial_capacity=args.partial_capacity,
@@ -510,6 +526,7 @@ def main():
                 return D.spgemm_row_sharded(ctx, np_dtype, n, n, n, ptrs, dist, rank, world, device, partial_capacity=args.partial_capacity,
                                             host_collectives=args.dist_backend == "gloo", checksum=checksum)
         dt, infos = timed(step, args.steps, args.warmup, sync, dist.barrier, reduce_max)
+        note(f"{mode}-sharded over {world} ranks: {dt / args.steps * 1e3:.1f} ms per step")
         chk = check_sum(step(checksum=True)["val_sum_global"], want_sum, args.dtype, f"{mode}-sharded")
         info = infos[-1]
         ms_step = dt / args.steps * 1e3

@@ -208,6 +208,7 @@ def spgemm_k_sharded(ctx, np_dtype, M, N, slab, dist, rank, world, partial_capac
     RCCL keeps everything in HBM."""
     Ks, csc, csr = slab
     device = csc[0].device
+    torch.cuda.synchronize(device)   # the operands may come from torch kernels still in flight; the library's stream does not wait
     ptrs = [t.data_ptr() for t in (*csc, *csr)]
     vt = "<f8" if np.dtype(np_dtype) == np.float64 else "<f4"
     tdt = torch.float64 if np.dtype(np_dtype) == np.float64 else torch.float32
@@ -276,6 +277,7 @@ def spgemm_row_sharded(ctx, np_dtype, M, K, N, ptrs, dist, rank, world, device, 
     """Row-sharded product: rank i computes the i-th of `world` output-row ranges (balanced by partial products, derived
     by every rank from the replicated operands alone).  No data-path collective; only the counters of the report are
     all-reduced.  ptrs: the six device addresses of CSC(A) / CSR(B)."""
+    torch.cuda.synchronize(device)   # (operands from torch kernels still in flight)
     res = ctx.spgemm_csc_csr_device(np_dtype, M, K, N, ptrs, validate=False, partial_capacity=partial_capacity,
                                     row_shard=(rank, world))
     info = dict(res.info)

@@ -203,7 +203,9 @@ class Context:
         return CsrResult(self, h)
 
     def spgemm_csc_csr_device(self, dtype, M, K, N, ptrs, *, validate=False, partial_capacity=0, k_range=None, row_shard=None):
-        """Same with six DEVICE addresses (ints): a_colptr, a_rowidx, a_vals, b_rowptr, b_colidx, b_vals."""
+        """Same with six DEVICE addresses (ints): a_colptr, a_rowidx, a_vals, b_rowptr, b_colidx, b_vals.
+        The arrays must be COMPLETE when this is called: the context works on a stream of its own (or the one it was
+        created on) and does not wait for kernels other streams -- e.g. torch's -- still have in flight on them."""
         cfg = self._config(validate, partial_capacity, k_range, row_shard)
         h = C.c_void_p()
         _lib.check(_lib.lib().osp_spgemm_csc_csr(self._h, _DT[np.dtype(dtype)], M, K, N,
