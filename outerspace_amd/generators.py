@@ -61,3 +61,19 @@ def coo_to_csr(nrow, rows, cols, vals):
 def coo_to_csc(ncol, rows, cols, vals):
     """COO -> CSC arrays (colptr i64, rowidx u32, vals)."""
     return coo_to_csr(ncol, cols, rows, vals)
+
+
+def mlp_layer_operands(H, threshold):
+    """BASELINE configs[4] at its stated shape, rebuilt from a seed: act_0 (1024 x 784, ~16 % dense, like a post-ReLU
+    activation) and fc1_weight (H x 784) pruned to |w| > threshold -- the inputs tests/golden/make_golden.py:case_mlp_full
+    fed to the compiled reference (the threshold it stored came from the reference's get_prune_threshold).
+    Returns (act f32 dense, pruned W f32 dense, COO of act, COO of W^T)."""
+    rng = np.random.default_rng(1024 + H)
+    W = (rng.standard_normal((H, 784)) * 0.05).astype(np.float32)
+    act = np.maximum(rng.standard_normal((1024, 784)).astype(np.float32) - np.float32(1.0), np.float32(0.0))
+    Wp = W * (np.abs(W) > np.float32(threshold))
+    ar, ac = np.nonzero(act)
+    wr, wc = np.nonzero(Wp)
+    a = (ar.astype(np.uint32), ac.astype(np.uint32), act[ar, ac])
+    b = (wc.astype(np.uint32), wr.astype(np.uint32), Wp[wr, wc])   # B = W^T: (k, out)
+    return act, W, Wp, a, b

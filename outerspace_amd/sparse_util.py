@@ -6,6 +6,7 @@ Mirrors, name for name, what a user of the reference imports today (all paths un
 * ``get_sparsity`` / ``get_prune_threshold`` / ``get_sparse_mask`` / ``prune_to_sparsity``
   -- ``sparse_util.py:5-22`` (including the SIGNED mask ``mat > threshold`` of ``:12-15``, which drops every
   negative weight; ``main.py:208-211`` prunes with ``|w| > threshold`` instead -- ``prune_by_magnitude``).
+  ``print_parameters_sparsity`` (``:24-30``) is training-side logging and is not mirrored.
 * ``save_tensor_as_mtx`` -- ``util.py:61-62`` (``scipy.io.mmwrite`` of the CSR form; byte-identical files).
 * ``sparse_linear`` / ``mlp_forward`` / ``mlp_forward_from_mtx`` -- the products the reference hands to its
   simulator one at a time (``get_mtx_files.py:76-96``: ``./simulator act_i.mtx fc{i+1}_weight.mtx`` computes
@@ -25,37 +26,33 @@ import torch
 from . import spgemm as _S
 
 
-# ---- sparse_util.py:5-30 ------------------------------------------------------------------------------
+# ---- the pruning helpers of sparse_util.py:5-22, same names and results (pinned to captured values) -------------------
 def get_sparsity(mat):
-    non_zeros_count = abs(mat).gt(0).sum()
-    return (non_zeros_count, torch.numel(mat), non_zeros_count / torch.numel(mat))
+    """(non-zero count, element count, density) -- the triple ``sparse_util.py:5-7`` returns (count and density as tensors)."""
+    nonzero = torch.count_nonzero(mat.abs() > 0)
+    total = mat.numel()
+    return nonzero, total, nonzero / total
 
 
 def get_prune_threshold(mat, sparsity_level):
-    return torch.quantile(abs(mat), 1 - sparsity_level)
+    """The |w| value below which all but a ``sparsity_level`` fraction of the entries lie (``sparse_util.py:9-10``)."""
+    return torch.quantile(mat.abs(), 1 - sparsity_level)
 
 
 def get_sparse_mask(mat, sparsity_level):
-    threshold = get_prune_threshold(mat, sparsity_level)
-    return mat > threshold  # signed, as in the reference (sparse_util.py:14)
+    """SIGNED comparison, as ``sparse_util.py:12-15`` does it: negative weights never pass."""
+    return mat > get_prune_threshold(mat, sparsity_level)
 
 
 def prune_to_sparsity(mat, sparsity_level):
-    if get_sparsity(mat)[2] <= sparsity_level:  # already at or below the desired level
-        return mat
-    return mat * get_sparse_mask(mat, sparsity_level)
+    """``sparse_util.py:17-22``: a matrix already at or below the level is returned as it is."""
+    _, _, density = get_sparsity(mat)
+    return mat if density <= sparsity_level else mat * get_sparse_mask(mat, sparsity_level)
 
 
 def prune_by_magnitude(mat, sparsity_level):
     """What ``main.py:208-211`` does per layer: keep ``|w| > quantile(|w|, 1 - s)``."""
     return mat * (mat.abs() > get_prune_threshold(mat, sparsity_level))
-
-
-def print_parameters_sparsity(model):
-    print("parameters sparsity: ")
-    for name, param in model.named_parameters():
-        if param.requires_grad:
-            print(name, get_sparsity(param))
 
 
 # ---- util.py:61-62 ------------------------------------------------------------------------------------
@@ -64,18 +61,37 @@ def save_tensor_as_mtx(a, save_file):
 
 
 # ---- the products -------------------------------------------------------------------------------------
+def _bias_relu_on_device(prod, bias, relu, dtype, device_index=0):
+    """``relu(prod + bias)`` for a CSR product, on the GPU: the product is scattered into a dense block in HBM, bias and
+    ReLU are applied there (a bias makes every entry of the row non-zero anyway), and what survives the ReLU comes back
+    as CSR.  ``models.py:17-31`` does the same three steps on dense tensors."""
+    dev = torch.device("cuda", device_index)
+    m, n = prod.shape
+    tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
+    dense = torch.zeros((m, n), dtype=tdt, device=dev)
+    if prod.nnz:
+        rows = torch.from_numpy(np.repeat(np.arange(m, dtype=np.int64), np.diff(prod.indptr))).to(dev)
+        dense[rows, torch.from_numpy(prod.indices.astype(np.int64)).to(dev)] = torch.from_numpy(prod.data.astype(dtype)).to(dev)
+    if bias is not None:
+        b = bias.detach() if hasattr(bias, "detach") else torch.as_tensor(np.asarray(bias))
+        dense += b.to(dev, tdt).reshape(1, -1)
+    if relu:
+        dense.clamp_(min=0)
+    nz = dense != 0
+    counts = nz.sum(dim=1)
+    indptr = np.zeros(m + 1, np.int64)
+    indptr[1:] = np.cumsum(counts.cpu().numpy())
+    cols = nz.nonzero()[:, 1]
+    return sp.csr_matrix((dense[nz].cpu().numpy(), cols.cpu().numpy(), indptr), shape=(m, n))
+
+
 def sparse_linear(act, weight, bias=None, relu=False, ctx=None, dtype=np.float32):
-    """``relu(act @ weight.T + bias)`` with the product on the GPU.  act: (batch x in), weight: (out x in), both
-    dense tensors / arrays or scipy sparse; returns scipy CSR (bias and ReLU are applied to the product)."""
+    """``relu(act @ weight.T + bias)``: the product on the GPU through the SpGEMM library, bias and ReLU on the GPU as
+    well.  act: (batch x in), weight: (out x in), both dense tensors / arrays or scipy sparse; returns scipy CSR."""
     prod = _S.spgemm(act, weight, transpose_b=True, ctx=ctx, dtype=dtype)
     if bias is None and not relu:
         return prod
-    out = prod.toarray()
-    if bias is not None:
-        out = out + np.asarray(bias.detach().cpu() if hasattr(bias, "detach") else bias, dtype=out.dtype).reshape(1, -1)
-    if relu:
-        out = np.maximum(out, 0)
-    return sp.csr_matrix(out)
+    return _bias_relu_on_device(prod, bias, relu, dtype, (ctx or _S.default_context()).device)
 
 
 def mlp_forward(x, layers, ctx=None, dtype=np.float32):

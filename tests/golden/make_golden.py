@@ -212,6 +212,47 @@ def case_mlp():
     print("mlp: P =", P, "nnzC =", len(r), "thr =", float(thr), "w nnz =", int(cnt))
 
 
+def mlp_full_inputs(H, thr=None):
+    """configs[4] at its stated shape: act_0 (1024 x 784, the reference's batch: config.py:2, get_mtx_files.py:19-73) and
+    fc1_weight (H x 784, models.py:10-14; H = 100, or 1000 in the saved logs), both from numpy's seeded generator so that
+    the tests can rebuild them without the reference.  Returns (act f32, W f32 dense, sparsity level)."""
+    rng = np.random.default_rng(1024 + H)
+    W = (rng.standard_normal((H, 784)) * 0.05).astype(np.float32)
+    act = np.maximum(rng.standard_normal((1024, 784)).astype(np.float32) - np.float32(1.0), np.float32(0.0))
+    level = 0.05 if H == 100 else 0.01   # "pruned to 1 % of the weights": saved_weights/MLP1/prune0p01_l2reg/log.txt
+    return act, W, level
+
+
+def case_mlp_full():
+    """BASELINE.json configs[4] at full shape (batch 1024, H in {100, 1000}): weights pruned with the REFERENCE's threshold
+    (sparse_util.py:9-10, in main.py:208-211's |w| > thr form), product act * W^T from the compiled reference in f32.
+    Stored: the threshold, digests of the structure, a sample of the values and the f64 dense values at the sample."""
+    import torch
+    sys.path.insert(0, REF_NN)
+    import sparse_util as ref_su
+    out = {}
+    for H in (100, 1000):
+        act, W, level = mlp_full_inputs(H)
+        thr = np.float32(ref_su.get_prune_threshold(torch.from_numpy(W), level))
+        Wp = W * (np.abs(W) > thr)
+        cnt, numel, frac = ref_su.get_sparsity(torch.from_numpy(Wp))
+        ar, ac = np.nonzero(act)
+        wr, wc = np.nonzero(Wp)
+        a = (ar.astype(np.uint32), ac.astype(np.uint32), act[ar, ac])
+        b = (wc.astype(np.uint32), wr.astype(np.uint32), Wp[wr, wc])          # B = W^T: (k, out)
+        r = _run_csx(1024, 784, H, a, b, np.float32)
+        rowptr, _, _ = oracle.coo_to_csr(1024, r["rows"], r["cols"], r["vals"])
+        idx = np.arange(0, r["nnzc"], 997, dtype=np.int64)
+        dense = (act.astype(np.float64) @ Wp.astype(np.float64).T)[r["rows"][idx], r["cols"][idx]]
+        out.update({f"thr_{H}": thr, f"level_{H}": np.float32(level), f"w_nnz_{H}": int(cnt), f"act_nnz_{H}": len(ar),
+                    f"in_sha_{H}": sha(act) + sha(W), f"P_{H}": r["partials"], f"nnzC_{H}": r["nnzc"],
+                    f"rowptr_sha_{H}": sha(rowptr.astype(np.int64)), f"colidx_sha_{H}": sha(r["cols"]),
+                    f"val_sum_{H}": np.float64(r["vals"].astype(np.float64).sum()), f"val_abs_max_{H}": np.float32(np.abs(r["vals"]).max()),
+                    f"sample_idx_{H}": idx, f"sample_val_{H}": r["vals"][idx].copy(), f"sample_dense_f64_{H}": dense})
+        print(f"mlp full H={H}: act nnz {len(ar)}, W nnz {int(cnt)} ({float(frac):.4f}), thr {float(thr):.6f}, P = {r['partials']}, nnzC = {r['nnzc']}")
+    np.savez_compressed(os.path.join(HERE, "mlp_full_expected.npz"), **out)
+
+
 if __name__ == "__main__":
     assert oracle.have_ref(), "build oracle/_ref first: make -C oracle"
     case_c1()
@@ -219,3 +260,4 @@ if __name__ == "__main__":
     case_edges()
     case_rmat()
     case_mlp()
+    case_mlp_full()

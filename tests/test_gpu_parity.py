@@ -246,6 +246,33 @@ def test_mlp_layer_f32(ctx, golden_dir):
     assert abs(out - sp.csr_matrix((g["vals"], (g["rows"], g["cols"])), shape=(64, 100))).max() < 1e-5
 
 
+@pytest.mark.parametrize("H", [100, 1000])
+def test_mlp_layer_full_shape_f32(ctx, port, golden_dir, H):
+    """BASELINE configs[4] at its stated shape (batch 1024, H = 100 and 1000), f32: the GPU bit for bit against the oracle,
+    within 1e-5 of the compiled reference's sample and of dense f64; then the same layer through the NN glue
+    (sparse_linear with bias and ReLU) against dense torch."""
+    import hashlib
+    import torch
+    from outerspace_amd import sparse_util as su
+    g = load(golden_dir, "mlp_full_expected.npz")
+    act, W, Wp, a, b = gen.mlp_layer_operands(H, g[f"thr_{H}"])
+    got, want = run_both(ctx, port, 1024, 784, H, a, b, np.float32)
+    assert_same(got, want)
+    sha = lambda x: hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest()
+    assert got.info["partials"] == int(g[f"P_{H}"]) and got.nnz == int(g[f"nnzC_{H}"])
+    assert sha(got.rowptr) == str(g[f"rowptr_sha_{H}"]) and sha(got.colidx) == str(g[f"colidx_sha_{H}"])
+    scale = float(g[f"val_abs_max_{H}"])
+    idx = g[f"sample_idx_{H}"]
+    assert np.abs(got.vals[idx] - g[f"sample_val_{H}"]).max() <= 1e-5 * scale
+    assert np.abs(got.vals[idx] - g[f"sample_dense_f64_{H}"]).max() <= 1e-5 * scale
+    # the layer as the model runs it: relu(act @ W^T + b)
+    bias = torch.linspace(-0.05, 0.05, H)
+    out = su.sparse_linear(torch.from_numpy(act), torch.from_numpy(Wp), bias, relu=True, ctx=ctx)
+    ref = torch.relu(torch.from_numpy(act).double() @ torch.from_numpy(Wp).double().T + bias.double()).numpy()
+    assert out.shape == (1024, H) and np.abs(out.toarray() - ref).max() <= 1e-5 * max(scale, 1.0)
+    assert out.nnz == int((out.toarray() != 0).sum())   # ReLU re-sparsified: no explicit zeros kept
+
+
 def test_properties_at_scale(ctx):
     """Size-independent checks on a product too large for the oracle in seconds:
     sorted unique columns, row sums (C*1 == A*(B*1)), and linearity in A's values."""

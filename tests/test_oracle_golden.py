@@ -149,6 +149,24 @@ def test_mlp_layer_f32(port, golden_dir):
     assert np.allclose(res["vals"], dense, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("H", [100, 1000])
+def test_mlp_layer_full_shape_f32(port, golden_dir, H):
+    """configs[4] at its stated shape: act_0 (1024 x 784) * fc1_weight (H x 784)^T, H = 100 (models.py:10-14) and 1000
+    (the saved logs), f32: the oracle against the compiled reference's digests and against dense f64."""
+    g = load(golden_dir, "mlp_full_expected.npz")
+    act, W, Wp, a, b = gen.mlp_layer_operands(H, g[f"thr_{H}"])
+    assert sha(act) + sha(W) == str(g[f"in_sha_{H}"]), "generator drifted"
+    assert len(a[0]) == int(g[f"act_nnz_{H}"]) and len(b[0]) == int(g[f"w_nnz_{H}"])
+    res, _ = spgemm_from_coo(port, 1024, 784, H, a, b, np.float32)
+    assert res["partials"] == int(g[f"P_{H}"]) and len(res["colidx"]) == int(g[f"nnzC_{H}"])
+    assert sha(res["rowptr"]) == str(g[f"rowptr_sha_{H}"]) and sha(res["colidx"]) == str(g[f"colidx_sha_{H}"])
+    scale = float(g[f"val_abs_max_{H}"])   # terms of both signs: 1e-5 of the largest entry
+    idx = g[f"sample_idx_{H}"]
+    assert np.abs(res["vals"][idx] - g[f"sample_val_{H}"]).max() <= 1e-5 * scale
+    assert np.abs(res["vals"][idx] - g[f"sample_dense_f64_{H}"]).max() <= 1e-5 * scale
+    assert np.isclose(res["vals"].astype(np.float64).sum(), float(g[f"val_sum_{H}"]), rtol=1e-5, atol=1e-5 * scale)
+
+
 def test_kslab_decomposition(port):
     """The outer product is k-separable: slab results sum to the full product."""
     n, rows, cols, vals = gen.rmat_coo(8, 8, "mild", seed=3)
