@@ -203,7 +203,13 @@ __global__ void split_vrows_kernel(uint32_t nheavy, const uint64_t *vbase, const
 }
 
 // One workgroup splits one long row of at most kSplitRowMax entries: histogram over its segments, scan, stable
-// scatter -- the row is read twice, the second time from L2.  No global histogram, no device-wide scan.
+// scatter -- the row is read twice, the second time from cache.  No global histogram, no device-wide scan.
+// Two variants were built, measured on R-MAT-22 (28 GB of long-row records per launch, 18.6 ms as it stands) and NOT kept:
+//   * segment counts from column-block tables of B's rows (257 prefix counts per row of B, built once per product) instead
+//     of the histogram pass: 17.4 ms, but 4 ms per product to build the table -- the histogram pass costs hardly more than
+//     a millisecond of the kernel, because it leaves the row in cache for the scatter pass;
+//   * the scatter staged through LDS (a round's records put in segment order inside the workgroup, then streamed out with
+//     consecutive threads on consecutive records): 18.9 ms -- the direct 12-byte stores are not what limits it.
 template <class T, bool RA>
 __global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
     const uint32_t *rows, uint32_t nheavy, const uint8_t *hbits, const uint32_t *nstretch, const uint64_t *vbase,
