@@ -133,3 +133,17 @@ def test_cli_under_sanitizers_fails_cleanly_without_gpu(golden_dir, tmp_path):
         r = subprocess.run([exe, a, os.path.join(golden_dir, "c1_B.mtx")], capture_output=True, text=True, timeout=120, env=env)
         assert r.returncode == 1 and "no CPU path" in r.stderr and "NNZ = 410" in r.stdout
         assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
+
+
+def test_integration_doc_quotes_the_compiled_binding():
+    """INTEGRATION.md section 2 shows integration/simspgemm_gpu_binding.h's function verbatim (the header is compiled
+    against the reference's common.h by `make -C oracle`, so the documented binding cannot drift from a working one)."""
+    hdr = open(os.path.join(ROOT, "integration", "simspgemm_gpu_binding.h")).read()
+    fn = hdr[hdr.index("inline COOMatrix cscMulcsrMergedGPU"):]
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert fn in doc
+    if os.path.exists("/root/reference/simulator/common.h"):   # build container: the demo that uses it has been built
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "all"], check=True, stdout=subprocess.DEVNULL)
+        for sfx in ("f32", "f64"):
+            assert os.path.exists(os.path.join(ROOT, "oracle", "_ref", f"binding_demo_{sfx}"))

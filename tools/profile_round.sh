@@ -8,15 +8,15 @@ O=$R/$1
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
-python3 $R/bench.py --rmat uniform --cpu-baseline 0 > $O/bench_uniform.json 2>/dev/null || exit 1
-python3 $R/bench.py --dtype f32 --cpu-baseline 0 > $O/bench_mild_f32.json 2>/dev/null || exit 1
+python3 $R/bench.py --rmat uniform --cpu-baseline 0 --extras 0 > $O/bench_uniform.json 2>/dev/null || exit 1
+python3 $R/bench.py --dtype f32 --cpu-baseline 0 --extras 0 > $O/bench_mild_f32.json 2>/dev/null || exit 1
 python3 $R/bench.py --workload webgoogle --cpu-baseline 0 --steps 20 --warmup 3 > $O/bench_webgoogle.json 2>/dev/null || exit 1
 python3 $R/bench.py --rmat g500 --scale 20 --stream-output --cpu-baseline 0 --steps 2 --warmup 1 > $O/bench_g500_20_streamed.json 2>/dev/null || exit 1
 for w in mild uniform; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$w -- python3 $R/bench.py --rmat $w --steps 3 --warmup 1 --cpu-baseline 0 > $O/ks_$w.json 2> $O/ks_$w.err || exit 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$w -- python3 $R/bench.py --rmat $w --steps 3 --warmup 1 --cpu-baseline 0 --extras 0 > $O/ks_$w.json 2> $O/ks_$w.err || exit 1
 done
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-baseline 0 > $O/pmc_$c.json 2> $O/pmc_$c.err || exit 1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-baseline 0 --extras 0 > $O/pmc_$c.json 2> $O/pmc_$c.err || exit 1
 done
 # keep only the small summaries (the traces themselves are large)
 for w in mild uniform; do
