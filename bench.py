@@ -364,10 +364,28 @@ def extra_workload(ctx, name, n, csr, csc, args, np_dtype, tdtype, device, E, st
             "result_check_rel_err": chk["rel_err"]}
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner and gloo a connection notice there (from C,
+    not through sys.stdout): keep the real stdout for the line and point descriptor 1 at stderr for everybody else."""
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    os.write(_JSON_FD if _JSON_FD is not None else 1, line)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))   # before anything here touches the GPU
+    claim_stdout()
 
     import torch
     from outerspace_amd import generators as gen
@@ -500,7 +518,7 @@ def main():
                 ctx.trim()
                 torch.cuda.empty_cache()
             out["extra_workloads"] = extras
-        print(json.dumps(out), flush=True)
+        emit(out)
         ctx.close()
         sys.exit(status)
 
@@ -560,7 +578,7 @@ def main():
             "phases_ms": head["rank0_phases_ms"], "roofline": head["rank0_roofline"], "result_check": head["result_check"],
             "decompositions": results,
         })
-        print(json.dumps(out), flush=True)
+        emit(out)
     ctx.close()
     dist.barrier()
     dist.destroy_process_group()
