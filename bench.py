@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--shard", default="both", choices=["both", "k", "rows"],
                     help="multi-GPU decomposition(s) to measure: k = shard the shared dimension, exchange partial CSRs over RCCL, "
                          "merge (the headline); rows = every rank computes a range of output rows from the replicated operands")
+    ap.add_argument("--k-exchange", default="raw", choices=["raw", "merged"],
+                    help="k-sharded product: what a rank sends -- raw = its partial products unmerged (one merge in all, bit-identical "
+                         "to one GPU; default) | merged = its partial CSR (less to send when the product compresses well)")
     ap.add_argument("--force-dist", type=int, default=0, help="run the distributed code paths even with one rank (sanity check)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal only: exchange staged through host memory, ranks may share a GPU")
@@ -287,27 +290,32 @@ def make_step(ctx, n, csr, csc, np_dtype, tdtype, device, partial_capacity, stre
 
 def kernel_roofline(infos, n, E):
     """Per-kernel roofline: algorithmic bytes per launch / mean launch duration, from
-    the HIP events the library records on its own stream around exactly those launches."""
+    the HIP events the library records on its own stream around exactly those launches.  In the k-sharded product the
+    multiply runs in the rank's local step and the merge in its final step (`final_info`): each kernel is priced on the
+    call it ran in."""
     info = infos[-1]
+    minfos = [i.get("final_info", i) for i in infos]   # where the merge (and the split) ran
+    minfo = minfos[-1]
 
-    def mean(key):
-        return float(np.mean([i[key] for i in infos]))
-    Pl, nnz_cl, nnz_al = info["partials"], info["nnz_c"], info["nnz_a"]  # this rank's product
+    def mean(key, src=None):
+        return float(np.mean([i[key] for i in (src or infos)]))
+    Pl, nnz_al = info["partials"], info["nnz_a"]  # this rank's product
     kernels = {}
     nmul = max(1, info["multiply_launches"])
-    nmer = max(1, info["merge_launches"])
+    nmer = max(1, minfo["merge_launches"])
+    nrows = int(minfo.get("M", n))
     mul_bytes = (E * (nnz_al + info["nnz_b"]) + 2 * 8 * (n + 1) + E * Pl) / nmul
-    mer_bytes = (E * Pl + E * nnz_cl + 8 * (n + 1)) / nmer
+    mer_bytes = (E * minfo["partials"] + E * minfo["nnz_c"] + 8 * (nrows + 1)) / nmer
     for name, nbytes, ms, nl in (("multiply_kernel", mul_bytes, mean("ms_multiply_kernel"), nmul),
-                                 ("merge_tiles_kernel", mer_bytes, mean("ms_merge_kernel"), nmer)):
+                                 ("merge_tiles_kernel", mer_bytes, mean("ms_merge_kernel", minfos), nmer)):
         per = ms / nl
         kernels[name] = {"algorithmic_bytes_per_launch": nbytes, "ms_per_launch": per, "launches_per_step": nl,
                          "GBps": (nbytes / (per * 1e-3) / 1e9) if per > 0 else 0.0}
-    if info.get("split_launches"):
-        # the one-workgroup split of long rows: reads and writes of every record it moves (DESIGN.md 3)
-        nsp = info["split_launches"]
-        per = mean("ms_split_kernel") / nsp
-        nbytes = float(info.get("split_bytes_per_partial", 3.0)) * E * info["split_partials"] / nsp
+    if minfo.get("split_launches"):
+        # the one-workgroup split of long rows: two reads and one write of every record it moves (DESIGN.md 3)
+        nsp = minfo["split_launches"]
+        per = mean("ms_split_kernel", minfos) / nsp
+        nbytes = 3.0 * E * minfo["split_partials"] / nsp
         kernels["split_row_kernel"] = {"algorithmic_bytes_per_launch": nbytes, "ms_per_launch": per, "launches_per_step": nsp,
                                        "GBps": (nbytes / (per * 1e-3) / 1e9) if per > 0 else 0.0}
     for k in kernels.values():
@@ -536,7 +544,7 @@ def main():
 
             def step(checksum=False):
                 return D.spgemm_k_sharded(ctx, np_dtype, n, n, slab, dist, rank, world, partial_capacity=args.partial_capacity,
-                                          stage_through_host=args.dist_backend == "gloo", checksum=checksum)
+                                          stage_through_host=args.dist_backend == "gloo", checksum=checksum, exchange=args.k_exchange)
         else:
             ptrs = [t.data_ptr() for t in (*csc, *csr)]
 
@@ -557,10 +565,12 @@ def main():
             sent = torch.tensor([info["bytes_sent"]], device=cdev, dtype=torch.int64)
             allsent = [torch.zeros_like(sent) for _ in range(world)]
             dist.all_gather(allsent, sent)
-            r.update(k_bounds=k_bounds, bytes_sent_per_rank=[int(x[0]) for x in allsent],
+            r.update(k_bounds=k_bounds, bytes_sent_per_rank=[int(x[0]) for x in allsent], exchange=info.get("exchange"),
                      row_bounds=info["row_bounds"], local_nnz_rank0=info["nnz_c"], final_merge_partials_rank0=info["final_merge_partials"],
-                     parallelism=f"k-sharded over {world} GPUs: each rank holds only its columns of A / rows of B, partial CSRs exchanged "
-                                 f"by one all-to-all-v over RCCL, merged per output-row range (result row-sharded)")
+                     parallelism=f"k-sharded over {world} GPUs: each rank holds only its columns of A / rows of B, "
+                                 + ("multiplies, and sends its partial products unmerged" if info.get("exchange") == "raw"
+                                    else "forms its partial CSR") +
+                                 ": one all-to-all-v over RCCL, one merge per output-row range (result row-sharded)")
             del slab
         else:
             r["parallelism"] = f"output rows sharded over {world} GPUs (operands replicated, result row-sharded, no exchange)"

@@ -198,6 +198,31 @@ int osp_merge_csr_parts(osp_context_t ctx, osp_dtype_t dtype, uint64_t M, uint64
                         const void *const *valss, osp_memspace_t space, const osp_config_t *cfg,
                         osp_result_t *result);
 
+/*
+ * The MULTIPLY phase alone -- cscMulcsr (SimSpGEMM.cpp:265-281) without deduplicateCOO: the partial products of
+ * C = A * B as they are staged, NOT merged.  Packed records {uint32 col; T val} (8 bytes for f32, 12 for f64; the layout
+ * of the reference's CSRElement), grouped by output row: row i owns records [rowptr[i], rowptr[i+1]) in ascending k,
+ * columns ascending inside one k; equal columns of different k are still separate records.  This is what a rank of the
+ * k-sharded multi-GPU product sends when the product hardly compresses (R-MAT: nnz(C) / P = 0.97): merging locally first
+ * would merge everything twice.  The receiver sums the parts with osp_merge_record_parts -- in part order, and inside a
+ * part in record order, i.e. in ascending k overall: the same order, and the same bits, as the single-GPU product.
+ * All P records are held at once (no row panels): OSP_ERR_ALLOC when they do not fit.
+ * osp_result_info: partials = nnz_c = P.  osp_result_copy_csr / osp_result_device_ptrs do not apply to such a result;
+ * use osp_result_partials (device pointers, valid until osp_result_destroy).
+ */
+int osp_spgemm_partials(osp_context_t ctx, osp_dtype_t dtype, uint64_t M, uint64_t K, uint64_t N,
+                        const int64_t *a_colptr, const uint32_t *a_rowidx, const void *a_vals,
+                        const int64_t *b_rowptr, const uint32_t *b_colidx, const void *b_vals,
+                        osp_memspace_t space, const osp_config_t *cfg, osp_result_t *result);
+int osp_result_partials(osp_result_t r, const int64_t **rowptr, const void **records);
+/*
+ * Sum `nparts` collections of records of identical shape (M rows, columns < N) into one CSR: rowptrs[p][M+1] offsets in
+ * records, records[p] packed {uint32 col; T val}; rows need be neither sorted nor free of duplicates.
+ */
+int osp_merge_record_parts(osp_context_t ctx, osp_dtype_t dtype, uint64_t M, uint64_t N, int nparts,
+                           const int64_t *const *rowptrs, const void *const *records, osp_memspace_t space,
+                           const osp_config_t *cfg, osp_result_t *result);
+
 /* ---- results --------------------------------------------------------------------------- */
 int osp_result_info(osp_result_t r, osp_result_info_t *info);
 /* Copy the CSR out.  rowptr[M+1], colidx[nnz_c], vals[nnz_c]; any pointer may be NULL. */

@@ -64,6 +64,7 @@ EXPORTS = [
     "osp_context_create", "osp_context_create_on_stream", "osp_context_destroy", "osp_context_trim",
     "osp_config_default", "osp_last_error_string", "osp_status_string", "osp_spgemm_csc_csr", "osp_spgemm_csc_csr_panels",
     "osp_spgemm_coo", "osp_spgemm_csc_csr_aos", "osp_context_alloc", "osp_context_free",
+    "osp_spgemm_partials", "osp_result_partials", "osp_merge_record_parts",
     "osp_merge_csr_parts", "osp_result_info", "osp_result_copy_csr", "osp_result_device_ptrs",
     "osp_result_destroy", "osp_mtx_read", "osp_host_free", "osp_coo_to_compressed_f32",
     "osp_coo_to_compressed_f64", "osp_spgemm_mtx", "osp_result_write_mtx",
@@ -108,6 +109,9 @@ def lib():
     L.osp_spgemm_csc_csr_panels.argtypes = [vp, i32, u64, u64, u64, vp, vp, vp, vp, vp, vp, i32, C.POINTER(Config), PANEL_FN, vp,
                                             C.POINTER(ResultInfo)]
     L.osp_spgemm_coo.argtypes = [vp, i32, u64, u64, u64, u64, vp, vp, vp, u64, vp, vp, vp, i32, C.POINTER(Config), C.POINTER(vp)]
+    L.osp_spgemm_partials.argtypes = [vp, i32, u64, u64, u64, vp, vp, vp, vp, vp, vp, i32, C.POINTER(Config), C.POINTER(vp)]
+    L.osp_result_partials.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.osp_merge_record_parts.argtypes = [vp, i32, u64, u64, i32, C.POINTER(vp), C.POINTER(vp), i32, C.POINTER(Config), C.POINTER(vp)]
     L.osp_merge_csr_parts.argtypes = [vp, i32, u64, u64, i32, C.POINTER(vp), C.POINTER(vp),
                                       C.POINTER(vp), i32, C.POINTER(Config), C.POINTER(vp)]
     L.osp_result_info.argtypes = [vp, C.POINTER(ResultInfo)]

@@ -237,6 +237,7 @@ struct Result {
     int64_t *rowptr = nullptr;
     uint32_t *colidx = nullptr;
     void *vals = nullptr;
+    bool partials = false;  // osp_spgemm_partials: rowptr = record offsets per row, vals = the packed records, no colidx
 };
 
 struct PhaseTimer {
@@ -869,6 +870,17 @@ template <class T> struct PartsProducer : Producer<T> {
     }
 };
 
+template <class T> struct RecordPartsProducer : Producer<T> {
+    Context *ctx;
+    const int64_t *const *d_rowptrs; const Part<T> *const *d_recs;
+    int nparts;
+    const uint64_t *row_off;
+    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &) override {
+        const uint64_t nr = r1 - r0;
+        parts_scatter_rec_kernel<T><<<grid_for(nr * kWave, 256), 256, 0, ctx->stream>>>(d_rowptrs, d_recs, nparts, r0, r1, row_off, base, stage);
+    }
+};
+
 // Copies an input array to the device when it lives on the host.
 template <class T>
 static const T *to_device(Scratch &sc, const T *p, uint64_t n, osp_memspace_t space, hipStream_t s) {
@@ -889,7 +901,7 @@ template <class T>
 static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint64_t N, const int64_t *a_colptr_in,
                         const uint32_t *a_rowidx_in, const T *a_vals_in, const int64_t *b_rowptr_in,
                         const uint32_t *b_colidx_in, const T *b_vals_in, osp_memspace_t space,
-                        const osp_config_t &cfg, const PanelSink *sink = nullptr) {
+                        const osp_config_t &cfg, const PanelSink *sink = nullptr, bool partials_only = false) {
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
     PhaseTimer tm(s);
@@ -1001,7 +1013,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     const char *algo_env = getenv("OSP_ALGORITHM");
     const int algo = algo_env ? (strcmp(algo_env, "rowwise") == 0 ? OSP_ALGO_ROWWISE : OSP_ALGO_OUTER) : cfg.algorithm;
     if (algo != OSP_ALGO_OUTER && algo != OSP_ALGO_ROWWISE) throw Error(OSP_ERR_ARG, "unknown algorithm");
-    const bool rowwise = algo == OSP_ALGO_ROWWISE && nnz && (uint64_t)nnz_b < 0xffffffffull && nnz < 0xffffffffull;
+    const bool rowwise = algo == OSP_ALGO_ROWWISE && nnz && (uint64_t)nnz_b < 0xffffffffull && nnz < 0xffffffffull && !partials_only;
     ChunkTable<T> ct{};
     uint32_t n_long_rows = 1;
     if (nnz == 0) {
@@ -1049,6 +1061,28 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     prod.scan_tmp = sc.get<uint64_t>(scan_scratch_entries(nk));
     prod.nothing_staged = rowwise && n_long_rows == 0;
 
+    if (partials_only) {
+        // osp_spgemm_partials: the multiply phase alone; offsets and records belong to the result
+        if (row_sharded) throw Error(OSP_ERR_ARG, "partial products of a row shard are not supported");
+        res->partials = true;
+        res->rowptr = (int64_t *)ctx->alloc((M + 1) * sizeof(int64_t));
+        OSP_HIP(hipMemcpyAsync(res->rowptr, row_off, (M + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+        res->vals = ctx->alloc(std::max<uint64_t>(P, 1) * sizeof(Part<T>));
+        res->info.panels = 1;
+        res->info.nnz_c = P;
+        res->info.row_begin = 0;
+        res->info.row_end = M;
+        tm.begin(PH_MUL);
+        if (P) prod.produce(0, M, true, 0, P, (Part<T> *)res->vals, tm);
+        tm.end(PH_MUL);
+        OSP_HIP(hipEventRecord(ev.b, s));
+        OSP_HIP(hipStreamSynchronize(s));
+        res->info.ms_total = ev.ms();
+        res->info.ms_symbolic = tm.total(PH_SYM);
+        res->info.ms_multiply = tm.total(PH_MUL);
+        res->info.ms_multiply_kernel = tm.total(PH_MUL_K);
+        return;
+    }
     // row-sharded: A holds this rank's rows only, so the staging offsets start at 0 at r_lo and P is the shard's count
     const uint64_t off_lo = 0, P_rows = P;
     merge_pipeline<T>(ctx, res, prod, M, N, row_off, P_rows, cfg.partial_capacity, tm, r_lo, r_hi, off_lo, sink,
@@ -1217,6 +1251,53 @@ static void merge_parts_impl(Context *ctx, Result *res, uint64_t M, uint64_t N, 
     res->info.ms_merge = tm.total(PH_MERGE);
     res->info.ms_compact = tm.total(PH_COMPACT);
     res->info.ms_multiply_kernel = tm.total(PH_MUL_K);
+    res->info.ms_merge_kernel = tm.total(PH_MERGE_K);
+    res->info.ms_split_kernel = tm.total(PH_SPLIT_K);
+}
+
+template <class T>
+static void merge_record_parts_impl(Context *ctx, Result *res, uint64_t M, uint64_t N, int nparts, const int64_t *const *rowptrs,
+                                    const void *const *records, osp_memspace_t space, const osp_config_t &cfg) {
+    hipStream_t s = ctx->stream;
+    Scratch sc(ctx);
+    PhaseTimer tm(s);
+    EventPair ev;
+    OSP_HIP(hipEventRecord(ev.a, s));
+    std::vector<const int64_t *> rp(nparts);
+    std::vector<const Part<T> *> rc(nparts);
+    uint64_t nnz_in = 0;
+    for (int p = 0; p < nparts; p++) {
+        rp[p] = to_device(sc, rowptrs[p], M + 1, space, s);
+        const int64_t n = (space == OSP_HOST) ? rowptrs[p][M] : d2h(rp[p] + M, s);
+        if (n < 0) throw Error(OSP_ERR_ARG, "negative record count in part");
+        rc[p] = to_device(sc, (const Part<T> *)records[p], (uint64_t)n, space, s);
+        nnz_in += (uint64_t)n;
+    }
+    res->info.nnz_a = nnz_in;
+    const int64_t **d_rp = (const int64_t **)sc.get<void *>(nparts);
+    const Part<T> **d_rc = (const Part<T> **)sc.get<void *>(nparts);
+    copy_h2d(d_rp, rp.data(), nparts * sizeof(void *), s);
+    copy_h2d(d_rc, rc.data(), nparts * sizeof(void *), s);
+    tm.begin(PH_SYM);
+    const uint64_t ncand = M * (uint64_t)nparts;  // candidate chunk (r, p) = row r of part p
+    uint64_t *row_off = sc.get<uint64_t>(M + 1);
+    uint64_t *offs = sc.get<uint64_t>(ncand + 1);
+    uint64_t *scan_tmp = sc.get<uint64_t>(scan_scratch_entries(ncand));
+    device_exclusive_scan<PartsChunkLen, uint64_t>(PartsChunkLen{d_rp, nparts}, ncand, offs, scan_tmp, s);
+    parts_rows_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(offs, nparts, M, row_off);
+    const uint64_t P = d2h(offs + ncand, s);
+    tm.end(PH_SYM);
+    res->info.partials = P;
+    RecordPartsProducer<T> prod;
+    prod.ctx = ctx; prod.d_rowptrs = d_rp; prod.d_recs = d_rc; prod.nparts = nparts; prod.row_off = row_off;
+    merge_pipeline<T>(ctx, res, prod, M, N, row_off, P, cfg.partial_capacity, tm);
+    OSP_HIP(hipEventRecord(ev.b, s));
+    OSP_HIP(hipStreamSynchronize(s));
+    res->info.ms_total = ev.ms();
+    res->info.ms_symbolic = tm.total(PH_SYM);
+    res->info.ms_multiply = tm.total(PH_MUL);
+    res->info.ms_merge = tm.total(PH_MERGE);
+    res->info.ms_compact = tm.total(PH_COMPACT);
     res->info.ms_merge_kernel = tm.total(PH_MERGE_K);
     res->info.ms_split_kernel = tm.total(PH_SPLIT_K);
 }
@@ -1525,6 +1606,82 @@ int osp_merge_csr_parts(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, uint6
     return OSP_OK;
 }
 
+int osp_spgemm_partials(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, uint64_t K, uint64_t N, const int64_t *a_colptr,
+                        const uint32_t *a_rowidx, const void *a_vals, const int64_t *b_rowptr, const uint32_t *b_colidx,
+                        const void *b_vals, osp_memspace_t space, const osp_config_t *cfg_, osp_result_t *result) {
+    Context *ctx = (Context *)ctx_;
+    if (!ctx || !result) return fail(OSP_ERR_ARG, "null context or result pointer");
+    if (!a_colptr || !b_rowptr) return fail(OSP_ERR_ARG, "null pointer array");
+    if (dtype != OSP_F32 && dtype != OSP_F64) return fail(OSP_ERR_ARG, "dtype must be OSP_F32 or OSP_F64");
+    if (space != OSP_HOST && space != OSP_DEVICE) return fail(OSP_ERR_ARG, "bad memory space");
+    if (M >= 0xffffffffull || N > 0xffffffffull || K >= 0xffffffffull) return fail(OSP_ERR_ARG, "dimension exceeds the u32 index type");
+    osp_config_t cfg;
+    if (cfg_) cfg = *cfg_; else osp_config_default(&cfg);
+    Result *res = new Result;
+    res->ctx = ctx;
+    res->dtype = dtype;
+    res->info.M = M; res->info.K = K; res->info.N = N; res->info.dtype = dtype;
+    try {
+        OSP_HIP(hipSetDevice(ctx->device));
+        if (dtype == OSP_F32)
+            spgemm_impl<float>(ctx, res, M, K, N, a_colptr, a_rowidx, (const float *)a_vals, b_rowptr, b_colidx, (const float *)b_vals,
+                               space, cfg, nullptr, true);
+        else
+            spgemm_impl<double>(ctx, res, M, K, N, a_colptr, a_rowidx, (const double *)a_vals, b_rowptr, b_colidx,
+                                (const double *)b_vals, space, cfg, nullptr, true);
+    } catch (const Error &e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        destroy_result(res);
+        return fail(e.status, "%s", e.what());
+    } catch (const std::exception &e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        destroy_result(res);
+        return fail(OSP_ERR_ALLOC, "%s", e.what());
+    }
+    *result = (osp_result_t)res;
+    return OSP_OK;
+}
+
+int osp_result_partials(osp_result_t r_, const int64_t **rowptr, const void **records) {
+    Result *r = (Result *)r_;
+    if (!r) return fail(OSP_ERR_ARG, "null result");
+    if (!r->partials) return fail(OSP_ERR_ARG, "not a result of osp_spgemm_partials");
+    if (rowptr) *rowptr = r->rowptr;
+    if (records) *records = r->vals;
+    return OSP_OK;
+}
+
+int osp_merge_record_parts(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, uint64_t N, int nparts, const int64_t *const *rowptrs,
+                           const void *const *records, osp_memspace_t space, const osp_config_t *cfg_, osp_result_t *result) {
+    Context *ctx = (Context *)ctx_;
+    if (!ctx || !result || !rowptrs || !records) return fail(OSP_ERR_ARG, "null argument");
+    if (nparts < 1) return fail(OSP_ERR_ARG, "nparts must be >= 1");
+    if (dtype != OSP_F32 && dtype != OSP_F64) return fail(OSP_ERR_ARG, "dtype must be OSP_F32 or OSP_F64");
+    if (space != OSP_HOST && space != OSP_DEVICE) return fail(OSP_ERR_ARG, "bad memory space");
+    if (M >= 0xffffffffull || N > 0xffffffffull) return fail(OSP_ERR_ARG, "dimension exceeds the u32 index type");
+    osp_config_t cfg;
+    if (cfg_) cfg = *cfg_; else osp_config_default(&cfg);
+    Result *res = new Result;
+    res->ctx = ctx;
+    res->dtype = dtype;
+    res->info.M = M; res->info.N = N; res->info.dtype = dtype;
+    try {
+        OSP_HIP(hipSetDevice(ctx->device));
+        if (dtype == OSP_F32) merge_record_parts_impl<float>(ctx, res, M, N, nparts, rowptrs, records, space, cfg);
+        else merge_record_parts_impl<double>(ctx, res, M, N, nparts, rowptrs, records, space, cfg);
+    } catch (const Error &e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        destroy_result(res);
+        return fail(e.status, "%s", e.what());
+    } catch (const std::exception &e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        destroy_result(res);
+        return fail(OSP_ERR_ALLOC, "%s", e.what());
+    }
+    *result = (osp_result_t)res;
+    return OSP_OK;
+}
+
 int osp_result_info(osp_result_t r_, osp_result_info_t *info) {
     Result *r = (Result *)r_;
     if (!r || !info) return fail(OSP_ERR_ARG, "null argument");
@@ -1535,6 +1692,7 @@ int osp_result_info(osp_result_t r_, osp_result_info_t *info) {
 int osp_result_copy_csr(osp_result_t r_, int64_t *rowptr, uint32_t *colidx, void *vals, osp_memspace_t space) {
     Result *r = (Result *)r_;
     if (!r) return fail(OSP_ERR_ARG, "null result");
+    if (r->partials) return fail(OSP_ERR_ARG, "a result of osp_spgemm_partials holds records, not a CSR: use osp_result_partials");
     OSP_GUARD_BEGIN
     OSP_HIP(hipSetDevice(r->ctx->device));
     hipStream_t s = r->ctx->stream;
@@ -1554,6 +1712,7 @@ int osp_result_copy_csr(osp_result_t r_, int64_t *rowptr, uint32_t *colidx, void
 int osp_result_device_ptrs(osp_result_t r_, const int64_t **rowptr, const uint32_t **colidx, const void **vals) {
     Result *r = (Result *)r_;
     if (!r) return fail(OSP_ERR_ARG, "null result");
+    if (r->partials) return fail(OSP_ERR_ARG, "a result of osp_spgemm_partials holds records, not a CSR: use osp_result_partials");
     if (rowptr) *rowptr = r->rowptr;
     if (colidx) *colidx = r->colidx;
     if (vals) *vals = r->vals;

@@ -1486,4 +1486,18 @@ __global__ void parts_scatter_kernel(const int64_t *const *rowptrs, const uint32
     }
 }
 
+// the same for parts given as packed records (osp_merge_record_parts): a part's row is copied as it stands
+template <class T>
+__global__ void parts_scatter_rec_kernel(const int64_t *const *rowptrs, const Part<T> *const *recs, int nparts, uint64_t r0, uint64_t r1,
+                                         const uint64_t *row_off, uint64_t base, Part<T> *stage) {
+    const uint64_t r = r0 + ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    if (r >= r1) return;
+    uint64_t dst = row_off[r] - base;
+    for (int p = 0; p < nparts; p++) {
+        const int64_t b = rowptrs[p][r], e = rowptrs[p][r + 1];
+        for (int64_t i = b + lane_id(); i < e; i += kWave) store_part_words(&stage[dst + (i - b)], load_part_words(&recs[p][i]));
+        dst += (uint64_t)(e - b);
+    }
+}
+
 }  // namespace osp

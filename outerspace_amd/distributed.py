@@ -21,6 +21,8 @@ import time
 import numpy as np
 import torch
 
+from ._lib import OspError as _OspError
+
 
 def plan_k_shards(a_colptr, b_rowptr, world):
     """Cut [0,K) into `world` slabs with ~equal partial products.  Returns a python list of world+1 bounds."""
@@ -87,26 +89,29 @@ def all_to_all_v(dst, src, recv_l, send_l, dist, world, group=None, max_bytes=No
                 o0 += o.numel()
 
 
-def exchange_partial_csr(rowptr, colidx, vals, dist, world, group=None, ncols=None, alloc=None, stats=None):
+def exchange_partial_csr(rowptr, colidx, vals, dist, world, group=None, ncols=None, alloc=None, stats=None, widths=(1, 1)):
     """All-to-all-v of a partial CSR (all M rows) so that rank h ends up with every rank's rows of range h.
 
-    rowptr int64 [M+1], colidx int32 [nnz], vals [nnz] -- torch tensors on the communication device.
+    rowptr int64 [M+1]; colidx [nnz * widths[0]], vals [nnz * widths[1]] -- the per-entry payload arrays, torch tensors on
+    the communication device (`vals` may be None: one payload array only, e.g. packed records viewed as 32-bit words,
+    widths = (3,) for {u32 col; f64 val}).
     ncols: number of columns of the matrix (bounds a row's entry count; None = unknown).
-    alloc(numel, like) -> 1-D tensor for the two large receive buffers (default torch.empty); the GPU path hands out
+    alloc(numel, like) -> 1-D tensor for the large receive buffers (default torch.empty); the GPU path hands out
     memory of the library's pool, so that what the local product has just released is reused.
     stats (dict, optional) receives bytes_sent (payload this rank sends to OTHER ranks) and row_bounds.
-    Returns (row_bounds, parts) where parts[g] = (rowptr_g int64 [nr+1], colidx_g, vals_g) for the rows
+    Returns (row_bounds, parts) where parts[g] = (rowptr_g int64 [nr+1], payload slices...) for the rows
     [row_bounds[rank], row_bounds[rank+1]) as computed by rank g.
     """
     rank = dist.get_rank(group)
     M = rowptr.numel() - 1
-    # a row of one rank's partial CSR holds at most ncols entries, the per-row sum over the ranks at most world * ncols:
-    # 32-bit counts only where both are known to fit
+    payloads = [(colidx, int(widths[0]))] + ([(vals, int(widths[1]))] if vals is not None else [])
+    # a row of one rank's partial CSR holds at most ncols entries (unmerged partial products: no such bound), the per-row
+    # sum over the ranks at most world * ncols: 32-bit counts only where both are known to fit
     cnt_dtype = torch.int32 if (ncols is not None and int(ncols) < (1 << 31)) else torch.int64
     rownnz = (rowptr[1:] - rowptr[:-1]).to(cnt_dtype)
     wide = ncols is None or world * int(ncols) >= (1 << 31)
     weight = rownnz.to(torch.int64).clone() if wide else rownnz.clone()   # (all_reduce works in place: never on rownnz itself)
-    dist.all_reduce(weight, group=group)  # sum over ranks of per-row nnz
+    dist.all_reduce(weight, group=group)  # sum over ranks of per-row entry counts
     rb = plan_row_ranges(weight, world)
     rb_t = torch.tensor(rb, device=rowptr.device, dtype=torch.int64)
     offs = rowptr[rb_t]                                   # element offset of each range in my arrays
@@ -122,26 +127,27 @@ def exchange_partial_csr(rowptr, colidx, vals, dist, world, group=None, ncols=No
     all_to_all_v(cnt_recv, rownnz, [nr] * world, row_send, dist, world, group)
     if alloc is None:
         alloc = lambda numel, like: torch.empty(numel, dtype=like.dtype, device=like.device)
-    col_recv = alloc(sum(recv_l), colidx)
-    val_recv = alloc(sum(recv_l), vals)
-    all_to_all_v(col_recv, colidx, recv_l, send_l, dist, world, group)
-    all_to_all_v(val_recv, vals, recv_l, send_l, dist, world, group)
+    received = []
+    for arr, wd in payloads:
+        buf = alloc(sum(recv_l) * wd, arr)
+        all_to_all_v(buf, arr, [x * wd for x in recv_l], [x * wd for x in send_l], dist, world, group)
+        received.append((buf, wd))
     if stats is not None:
         away = sum(send_l) - send_l[rank]
-        stats["bytes_sent"] = (away * (colidx.element_size() + vals.element_size()) + rownnz.element_size() * (M - row_send[rank])
+        stats["bytes_sent"] = (away * sum(arr.element_size() * wd for arr, wd in payloads) + rownnz.element_size() * (M - row_send[rank])
                                + 8 * (world - 1))
         stats["row_bounds"] = list(rb)
     parts, o = [], 0
     for g in range(world):
         rp = torch.zeros(nr + 1, dtype=torch.int64, device=rowptr.device)
         rp[1:] = torch.cumsum(cnt_recv[g * nr:(g + 1) * nr].to(torch.int64), 0)
-        parts.append((rp, col_recv[o:o + recv_l[g]], val_recv[o:o + recv_l[g]]))
+        parts.append((rp,) + tuple(buf[o * wd:(o + recv_l[g]) * wd] for buf, wd in received))
         o += recv_l[g]
     return rb, parts
 
 
 def k_sharded_product(local_product, merge_parts, k_bounds, dist, world, group=None, sync=None, ncols=None, alloc=None,
-                      after_exchange=None, stats=None):
+                      after_exchange=None, stats=None, widths=(1, 1)):
     """Generic driver: local slab product -> exchange -> local merge.
 
     local_product(k0, k1) -> (rowptr, colidx, vals) tensors (partial CSR over all rows)
@@ -152,14 +158,15 @@ def k_sharded_product(local_product, merge_parts, k_bounds, dist, world, group=N
     """
     rank = dist.get_rank(group)
     t0 = time.perf_counter()
-    rowptr, colidx, vals = local_product(k_bounds[rank], k_bounds[rank + 1])
+    local = local_product(k_bounds[rank], k_bounds[rank + 1])   # (rowptr, colidx, vals) or (rowptr, packed records)
+    rowptr, colidx, vals = local if len(local) == 3 else (local[0], local[1], None)
     if sync:
         sync()
     t1 = time.perf_counter()
-    rb, parts = exchange_partial_csr(rowptr, colidx, vals, dist, world, group, ncols=ncols, alloc=alloc, stats=stats)
+    rb, parts = exchange_partial_csr(rowptr, colidx, vals, dist, world, group, ncols=ncols, alloc=alloc, stats=stats, widths=widths)
     if sync:
         sync()
-    del rowptr, colidx, vals
+    del rowptr, colidx, vals, local
     if after_exchange:
         after_exchange()
     t2 = time.perf_counter()
@@ -183,6 +190,15 @@ def _as_tensor(ptr, n, typestr, device, dtype):
     return torch.as_tensor(_DevArray(ptr, n, typestr), device=device)
 
 
+def _records_fit(ctx, csc, csr, np_dtype):
+    """Can this rank hold all partial products of its slab at once, beside what it receives and merges?  P * E for the
+    records it forms, the same again for the ones it receives, and the merge's staging on top: a quarter of the device."""
+    w = (csc[0][1:] - csc[0][:-1]) * (csr[0][1:] - csr[0][:-1])
+    P = int(w.sum())
+    free_b, total_b = torch.cuda.mem_get_info(csc[0].device)
+    return P * (4 + np.dtype(np_dtype).itemsize) < total_b // 4
+
+
 def slice_k_slab(csc, csr, k0, k1):
     """The operands of one k shard: columns [k0,k1) of A (CSC) and rows [k0,k1) of B (CSR) as arrays of their own
     (pointers rebased to 0) -- all a rank of the k-sharded product holds ("only its columns of A and rows
@@ -195,10 +211,19 @@ def slice_k_slab(csc, csr, k0, k1):
 
 
 def spgemm_k_sharded(ctx, np_dtype, M, N, slab, dist, rank, world, partial_capacity=0, stage_through_host=False, checksum=False,
-                     fetch=False):
+                     fetch=False, exchange="raw"):
     """The GPU instantiation used by bench.py.  slab = slice_k_slab(...) of THIS rank: (K', csc', csr') CUDA tensors.
     Returns an info dict (the local product's counters plus the exchange / final-merge figures); fetch=True adds
     info["final_csr"] = this rank's rows of C as host arrays (rowptr, colidx, vals) -- tests only.
+
+    exchange="raw" (default): the rank runs the MULTIPLY phase only (``osp_spgemm_partials``) and sends its partial
+    products as they are staged -- packed records grouped by output row, ascending k inside a row; the owner of a row range
+    merges everything ONCE (``osp_merge_record_parts``), parts in rank order = ascending k, which is the single-GPU
+    summation order: the result is bit-identical to the one-GPU product.  R-MAT products hardly compress (nnz(C)/P = 0.97),
+    so a local merge would shrink the exchange by 3 % and cost a whole merge pass.
+    exchange="merged": local product to a partial CSR first, the partial CSRs exchanged and merged (the round-1 form):
+    less to send when the product compresses well (Graph500 parameters: x2.2).  Falls back to this when the records do not
+    fit the device at once.
 
     Memory: the exchange receives into buffers of the library's pool (the staging memory the local product has just given
     back), and the local partial CSR is released as soon as the exchange has completed, before the final merge allocates.
@@ -214,7 +239,23 @@ def spgemm_k_sharded(ctx, np_dtype, M, N, slab, dist, rank, world, partial_capac
     tdt = torch.float64 if np.dtype(np_dtype) == np.float64 else torch.float32
     keep, pooled, stats = {}, [], {}
 
+    words = 1 + np.dtype(np_dtype).itemsize // 4   # 32-bit words per packed record
+    mode = {"exchange": exchange}
+
     def local_product(_k0, _k1):
+        if mode["exchange"] == "raw":
+            try:
+                res = ctx.spgemm_partials_device(np_dtype, M, Ks, N, ptrs)
+            except _OspError as e:
+                if e.status != 3:   # anything but "does not fit": a real error
+                    raise
+                mode["exchange"] = "merged"
+        if mode["exchange"] == "raw":
+            keep["local"] = res
+            keep["local_info"] = dict(res.info)
+            rp, rec = res.partials_ptrs()
+            out = (_as_tensor(rp, M + 1, "<i8", device, torch.int64), _as_tensor(rec, res.nnz * words, "<i4", device, torch.int32))
+            return tuple(t.cpu() for t in out) if stage_through_host else out
         res = ctx.spgemm_csc_csr_device(np_dtype, M, Ks, N, ptrs, validate=False, partial_capacity=partial_capacity)
         keep["local"] = res
         keep["local_info"] = dict(res.info)
@@ -238,14 +279,27 @@ def spgemm_k_sharded(ctx, np_dtype, M, N, slab, dist, rank, world, partial_capac
             parts = [tuple(t.to(device) for t in p) for p in parts]
             keep["parts"] = parts
         torch.cuda.current_stream().synchronize()  # received data must have landed
-        res = ctx.merge_csr_parts_device(np_dtype, nrows, N, [(r.data_ptr(), c.data_ptr(), v.data_ptr()) for r, c, v in parts],
-                                         partial_capacity=partial_capacity)
+        if mode["exchange"] == "raw":
+            res = ctx.merge_record_parts_device(np_dtype, nrows, N, [(r.data_ptr(), c.data_ptr()) for r, c in parts],
+                                                partial_capacity=partial_capacity)
+        else:
+            res = ctx.merge_csr_parts_device(np_dtype, nrows, N, [(r.data_ptr(), c.data_ptr(), v.data_ptr()) for r, c, v in parts],
+                                             partial_capacity=partial_capacity)
         keep["final"] = res
         return res.device_ptrs()
 
     try:
+        # every rank must take the same form of exchange: agree on it before the first collective (a rank whose records do
+        # not fit turns all of them to the merged form)
+        if mode["exchange"] == "raw":
+            need = torch.tensor([1 if _records_fit(ctx, csc, csr, np_dtype) else 0], device="cpu" if stage_through_host else device)
+            dist.all_reduce(need, op=dist.ReduceOp.MIN)
+            if int(need[0]) == 0:
+                mode["exchange"] = "merged"
+        raw = mode["exchange"] == "raw"
         out = k_sharded_product(local_product, merge_parts, [0] * (rank + 1) + [Ks] * (world - rank), dist, world,
-                                sync=torch.cuda.synchronize, ncols=N, alloc=pool_alloc, after_exchange=release_local, stats=stats)
+                                sync=torch.cuda.synchronize, ncols=None if raw else N, alloc=pool_alloc, after_exchange=release_local,
+                                stats=stats, widths=(words,) if raw else (1, 1))
         info = keep["local_info"]
         fin = keep["final"].info
         tot = torch.tensor([fin["nnz_c"], info["partials"]], device="cpu" if stage_through_host else device, dtype=torch.int64)
@@ -253,7 +307,8 @@ def spgemm_k_sharded(ctx, np_dtype, M, N, slab, dist, rank, world, partial_capac
         info.update(nnz_c_global=int(tot[0]), partials_global=int(tot[1]), nnz_c_final_local=fin["nnz_c"],
                     ms_local=out["seconds"][0] * 1e3, ms_exchange=out["seconds"][1] * 1e3,
                     ms_final_merge=out["seconds"][2] * 1e3, final_merge_partials=fin["partials"],
-                    bytes_sent=stats.get("bytes_sent", 0), row_bounds=stats.get("row_bounds"))
+                    bytes_sent=stats.get("bytes_sent", 0), row_bounds=stats.get("row_bounds"), exchange=mode["exchange"],
+                    final_info=dict(fin))
         if checksum:  # sum of all values of C (all ranks), for the 1^T C 1 = (1^T A)(B 1) sanity check
             _, _, va = keep["final"].device_ptrs()
             vs = _as_tensor(va, fin["nnz_c"], vt, device, tdt).sum(dtype=torch.float64).reshape(1)

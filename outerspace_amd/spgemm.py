@@ -55,6 +55,13 @@ class CsrResult:
     colidx = property(lambda self: self.to_host()[1])
     vals = property(lambda self: self.to_host()[2])
 
+    def partials_ptrs(self):
+        """Result of ``spgemm_partials_device``: (rowptr, records) device addresses -- int64 record offsets per row, packed
+        ``{u32 col; T val}`` records -- valid until ``close()``."""
+        r, rec = C.c_void_p(), C.c_void_p()
+        _lib.check(_lib.lib().osp_result_partials(self._h, C.byref(r), C.byref(rec)))
+        return r.value or 0, rec.value or 0
+
     def device_ptrs(self):
         """(rowptr, colidx, vals) device addresses, valid until ``close()``."""
         r, c, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -211,6 +218,28 @@ class Context:
         _lib.check(_lib.lib().osp_spgemm_csc_csr(self._h, _DT[np.dtype(dtype)], M, K, N,
                                                  *[C.c_void_p(int(p)) for p in ptrs], _lib.OSP_DEVICE,
                                                  C.byref(cfg), C.byref(h)))
+        return CsrResult(self, h)
+
+    def spgemm_partials_device(self, dtype, M, K, N, ptrs, *, k_range=None):
+        """The multiply phase alone (``osp_spgemm_partials``): the product's partial products, unmerged, as packed records
+        grouped by output row.  ``ptrs`` = six DEVICE addresses as in ``spgemm_csc_csr_device``.  ``result.nnz`` = P;
+        ``result.partials_ptrs()`` borrows the arrays."""
+        cfg = self._config(False, 0, k_range)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().osp_spgemm_partials(self._h, _DT[np.dtype(dtype)], M, K, N, *[C.c_void_p(int(p)) for p in ptrs],
+                                                  _lib.OSP_DEVICE, C.byref(cfg), C.byref(h)))
+        return CsrResult(self, h)
+
+    def merge_record_parts_device(self, dtype, M, N, part_ptrs, *, partial_capacity=0):
+        """Sum parts given as (rowptr, records) DEVICE addresses (``osp_merge_record_parts``) into one CSR."""
+        n = len(part_ptrs)
+        rp, rc = (C.c_void_p * n)(), (C.c_void_p * n)()
+        for i, (r, c) in enumerate(part_ptrs):
+            rp[i], rc[i] = int(r), int(c)
+        cfg = self._config(False, partial_capacity, None)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().osp_merge_record_parts(self._h, _DT[np.dtype(dtype)], M, N, n, rp, rc, _lib.OSP_DEVICE, C.byref(cfg),
+                                                     C.byref(h)))
         return CsrResult(self, h)
 
     def spgemm_csc_csr_panels(self, dtype, M, K, N, ptrs, on_panel, *, device=True, validate=False, partial_capacity=0,
