@@ -403,6 +403,30 @@ static void copy_d2h(void *dst, const void *src, size_t bytes, hipStream_t s) {
     OSP_HIP(hipEventSynchronize(pb.done[i ^ 1]));
     memcpy((char *)dst + off_prev, pb.p + (i ^ 1) * chunk, n_prev);
 }
+// several device scalars with ONE wait: a blocking read-back is a stream round trip, and a small product makes a dozen
+struct Gather {
+    hipStream_t s;
+    char *pin;
+    size_t used = 0;
+    std::vector<std::pair<void *, std::pair<size_t, size_t>>> outs;  // host destination, (offset in the pinned buffer, bytes)
+    explicit Gather(hipStream_t st) : s(st) {
+        Pinned &pb = pinned_buffer();
+        pb.reserve(4096);
+        pin = pb.p;
+    }
+    template <class T> void add(T *host_dst, const T *dptr) {
+        if (used + sizeof(T) > 4096) throw Error(OSP_ERR_ARG, "too many values in one read-back");
+        OSP_HIP(hipMemcpyAsync(pin + used, dptr, sizeof(T), hipMemcpyDeviceToHost, s));
+        outs.push_back({host_dst, {used, sizeof(T)}});
+        used += (sizeof(T) + 7) & ~size_t(7);
+    }
+    void wait() {
+        OSP_HIP(hipStreamSynchronize(s));
+        for (auto &o : outs) memcpy(o.first, pin + o.second.first, o.second.second);
+        outs.clear();
+        used = 0;
+    }
+};
 template <class T> static T d2h(const T *dptr, hipStream_t s) {
     T v;
     copy_d2h(&v, dptr, sizeof(T), s);
@@ -456,14 +480,17 @@ static TilePlan plan_tiles(Context *ctx, Scratch &sc, const uint64_t *row_off, u
     uint32_t *cb_cnt = sc.get<uint32_t>((uint64_t)ncb + 1);
     tile_walk_kernel<<<grid_for(ncb, 128), 128, 0, s>>>(tmp_rows, ncb, r1, row_off, cap, max_rows, nullptr, cb_cnt, nullptr);
     device_exclusive_scan<LoadU32, uint32_t>(LoadU32{cb_cnt}, ncb, cb_cnt, (uint32_t *)scan_tmp, s);
-    pl.ntiles = d2h(cb_cnt + ncb, s);
+    // the long rows' list needs nothing of the tile list: its scan runs before the tile count is read back, and both
+    // counts come home with one wait
+    HeavyRowFlag hrf{row_off, r0, cap};
+    uint32_t *long_scan = sc.get<uint32_t>(nr + 1);
+    uint32_t *long_tmp = sc.get<uint32_t>(scan_scratch_entries(std::max<uint64_t>(nr + 1, 16)));
+    device_exclusive_scan<HeavyRowFlag, uint32_t>(hrf, nr, long_scan, long_tmp, s);
+    pl.long_rows = sc.get<uint32_t>(nr + 1);
+    compact_flagged_kernel<HeavyRowFlag><<<grid_for(nr, 256), 256, 0, s>>>(hrf, long_scan, nr, r0, pl.long_rows);
+    { Gather g(s); g.add(&pl.ntiles, (const uint32_t *)cb_cnt + ncb); g.add(&pl.nlong, (const uint32_t *)long_scan + nr); g.wait(); }
     pl.tile_rows = sc.get<uint32_t>((uint64_t)pl.ntiles + 1);
     tile_walk_kernel<<<grid_for(ncb, 128), 128, 0, s>>>(tmp_rows, ncb, r1, row_off, cap, max_rows, cb_cnt, nullptr, pl.tile_rows);
-    HeavyRowFlag hrf{row_off, r0, cap};
-    device_exclusive_scan<HeavyRowFlag, uint32_t>(hrf, nr, flag_scan, (uint32_t *)scan_tmp, s);
-    pl.long_rows = sc.get<uint32_t>(nr + 1);
-    compact_flagged_kernel<HeavyRowFlag><<<grid_for(nr, 256), 256, 0, s>>>(hrf, flag_scan, nr, r0, pl.long_rows);
-    pl.nlong = d2h(flag_scan + nr, s);
     return pl;
 }
 
@@ -498,10 +525,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         uint64_t *hoff = sc.get<uint64_t>((uint64_t)nlong + 1);
         uint64_t *hscan_tmp = sc.get<uint64_t>(scan_scratch_entries(nlong));
         device_exclusive_scan<HeavyLen, uint64_t>(HeavyLen{p0.long_rows, io.row_off}, nlong, hoff, hscan_tmp, s);
-        const uint64_t nh = d2h(hoff + nlong, s);
-        if (nh >= 0xffffffffull) throw Error(OSP_ERR_CAPACITY, "long rows of one panel exceed 2^32 partial products");
-        res->info.heavy_rows += nlong;
-        res->info.heavy_partials += nh;
+        // (read back below, together with the split's sizes: one wait instead of four)
         // ---- one stable split by column range into the second buffer ----
         uint8_t *hbits = sc.get<uint8_t>(nlong);
         uint32_t *nstretch = sc.get<uint32_t>(nlong), *nseg = sc.get<uint32_t>(nlong);
@@ -514,7 +538,16 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nstretch}, nlong, blkbase, hscan_tmp, s);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nseg}, nlong, vbase, hscan_tmp, s);
         device_exclusive_scan<LoadU64, uint64_t>(LoadU64{nhist}, nlong, hbase, hscan_tmp, s);
-        const uint64_t nblocks = d2h(blkbase + nlong, s), nvirt = d2h(vbase + nlong, s), ncell = d2h(hbase + nlong, s);
+        uint64_t nh = 0, nblocks = 0, nvirt = 0, ncell = 0;
+        {
+            Gather g(s);
+            g.add(&nh, (const uint64_t *)hoff + nlong); g.add(&nblocks, (const uint64_t *)blkbase + nlong);
+            g.add(&nvirt, (const uint64_t *)vbase + nlong); g.add(&ncell, (const uint64_t *)hbase + nlong);
+            g.wait();
+        }
+        if (nh >= 0xffffffffull) throw Error(OSP_ERR_CAPACITY, "long rows of one panel exceed 2^32 partial products");
+        res->info.heavy_rows += nlong;
+        res->info.heavy_partials += nh;
         if (ncell >= 0xffffffffull || nblocks >= 0x7fffffffull || nvirt >= 0xffffffffull)
             throw Error(OSP_ERR_CAPACITY, "split histogram too large");
         if (getenv("OSP_VERBOSE"))
@@ -913,7 +946,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     const int64_t *b_rowptr = to_device(sc, b_rowptr_in, K + 1, space, s);
     int64_t nnz_a, nnz_b;
     if (space == OSP_HOST) { nnz_a = a_colptr_in[K]; nnz_b = b_rowptr_in[K]; }
-    else { nnz_a = d2h(a_colptr + K, s); nnz_b = d2h(b_rowptr + K, s); }
+    else { Gather g(s); g.add(&nnz_a, a_colptr + K); g.add(&nnz_b, b_rowptr + K); g.wait(); }
     if (nnz_a < 0 || nnz_b < 0) throw Error(OSP_ERR_ARG, "negative nnz in pointer array");
     if ((uint64_t)nnz_a >= 0xffffffffull || (uint64_t)nnz_b >= 0xffffffffull)
         throw Error(OSP_ERR_ARG, "operands with >= 2^32 non-zeros are not supported");
@@ -929,12 +962,15 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         OSP_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(uint32_t), s));
         validate_ptr_kernel<<<grid_for(K + 1, 256), 256, 0, s>>>(a_colptr, K, nnz_a, flags);
         validate_ptr_kernel<<<grid_for(K + 1, 256), 256, 0, s>>>(b_rowptr, K, nnz_b, flags + 1);
-        check_flags(d2h(flags, s), "A (CSC)");
-        check_flags(d2h(flags + 1, s), "B (CSR)");
+        uint32_t fa = 0, fb = 0;
+        { Gather g(s); g.add(&fa, (const uint32_t *)flags); g.add(&fb, (const uint32_t *)flags + 1); g.wait(); }
+        check_flags(fa, "A (CSC)");
+        check_flags(fb, "B (CSR)");
         if (nnz_a) validate_idx_kernel<<<grid_for(nnz_a, 256), 256, 0, s>>>(a_colptr, a_rowidx, K, nnz_a, M, flags);
         if (nnz_b) validate_idx_kernel<<<grid_for(nnz_b, 256), 256, 0, s>>>(b_rowptr, b_colidx, K, nnz_b, N, flags + 1);
-        check_flags(d2h(flags, s), "A (CSC)");
-        check_flags(d2h(flags + 1, s), "B (CSR)");
+        { Gather g(s); g.add(&fa, (const uint32_t *)flags); g.add(&fb, (const uint32_t *)flags + 1); g.wait(); }
+        check_flags(fa, "A (CSC)");
+        check_flags(fb, "B (CSR)");
     }
 
     // ---- k shard ----
@@ -947,7 +983,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     int64_t e0 = 0, e1 = nnz_a;
     if (k0 != 0 || k1 != K) {
         if (space == OSP_HOST) { e0 = a_colptr_in[k0]; e1 = a_colptr_in[k1]; }
-        else { e0 = d2h(a_colptr + k0, s); e1 = d2h(a_colptr + k1, s); }
+        else { Gather g(s); g.add(&e0, a_colptr + k0); g.add(&e1, a_colptr + k1); g.wait(); }
     }
     // ---- row-sharded multi-GPU mode: find this rank's rows and drop the rest of A BEFORE the symbolic phase ----
     // (a rank then sorts 1/G of A's non-zeros instead of all of them; every rank derives the same bounds from the

@@ -723,3 +723,30 @@ def test_rmat22_full_size_properties_and_slab_parity(ctx, port):
     del rowptr, colidx, vals, a2
     ctx.trim()
     torch.cuda.empty_cache()
+
+
+def test_ballot_rank_fallback_is_exact(port, monkeypatch):
+    """Every ranking kernel is compiled twice: stable ranks from the return order of one LDS atomic (the default, after a
+    self-test of that undocumented property when the context is created) and from ballot matching (what a context falls
+    back to when the self-test fails).  OSP_RANK=ballot forces the fallback: same bits as the oracle on inputs that reach
+    every ranking kernel -- tile sort, both long-row splits, the global-sort path, the symbolic sort, the device ingest."""
+    from outerspace_amd import spgemm as S
+    monkeypatch.setenv("OSP_RANK", "ballot")
+    with S.Context(0) as c:
+        for algo in ("outer", "rowwise"):
+            c.algorithm = algo
+            for preset, scale, dt in (("g500", 13, np.float64), ("mild", 12, np.float32)):
+                n, rows, cols, vals = gen.rmat_coo(scale, 16, preset, seed=5, dtype=dt)
+                got, want = run_both(c, port, n, n, n, (rows, cols, vals), (rows, cols, vals), dt)
+                assert got.info["heavy_rows"] > 0
+                assert_same(got, want)
+        monkeypatch.setenv("OSP_SPLIT_ROW_MAX", "0")      # every long row through the stretch split
+        monkeypatch.setenv("OSP_BIGTILE_CAP", "0")        # every over-long segment through the global sort
+        n, rows, cols, vals = gen.rmat_coo(12, 16, "g500", seed=6)
+        got, want = run_both(c, port, n, n, n, (rows, cols, vals), (rows, cols, vals), np.float64)
+        assert got.info["sorted_segments"] > 0
+        assert_same(got, want)
+        rng = np.random.default_rng(3)
+        p = rng.permutation(len(rows))
+        got = c.spgemm_coo(n, n, n, (rows[p], cols[p], vals[p]), (rows, cols, vals))
+        assert_same(got, want)
