@@ -104,6 +104,7 @@ typedef struct osp_result_info {
     uint32_t split_launches;
     uint64_t split_partials;    /* partial products those launches moved (lower bound: heavy_partials minus the
                                    capacity of the stretch-split jobs) */
+    uint64_t dense_segments;    /* over-long segments of hub rows reduced by dense accumulation (no sort) */
 } osp_result_info_t;
 
 /* ---- context ------------------------------------------------------------------------- */

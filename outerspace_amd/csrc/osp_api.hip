@@ -588,17 +588,42 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
             seg_src = sc.get<uint64_t>(nseg_long);
             seg_nnz = sc.get<uint32_t>(nvirt + 1);
             lv.heavy_nnz[1] = seg_nnz;
-            // by length: up to kBigTileCap -> one big LDS tile each, reduced in place; beyond -> global sort
+            // first those whose column range is narrow (hub rows): one dense accumulator per column, no sort at all
+            // (debugging aid: OSP_DENSE_SEG=0 leaves them to the two paths below)
+            const uint32_t *rest_list = p1.long_rows;
+            uint32_t nrest = nseg_long;
             uint32_t *hscan = sc.get<uint32_t>((uint64_t)nseg_long + 1);
             uint64_t *sscan_tmp = sc.get<uint64_t>(scan_scratch_entries(nseg_long));  // NOT hscan_tmp: that one is sized for nlong
-            // (debugging aid: OSP_BIGTILE_CAP=0 sends every over-long segment down the global-sort path)
+            {
+                const SegDenseFlag df{p1.long_rows, vbase, hbits, nlong, colbits, getenv("OSP_DENSE_SEG") ? atoi(getenv("OSP_DENSE_SEG")) : 1};
+                device_exclusive_scan<SegDenseFlag, uint32_t>(df, nseg_long, hscan, (uint32_t *)sscan_tmp, s);
+                const uint32_t ndense = d2h(hscan + nseg_long, s);
+                if (ndense) {
+                    uint32_t *dense_list = sc.get<uint32_t>(ndense), *others = sc.get<uint32_t>(nseg_long - ndense);
+                    seg_split_list_kernel<SegDenseFlag><<<grid_for(nseg_long, 256), 256, 0, s>>>(df, hscan, nseg_long, dense_list, others);
+                    dense_segment_kernel<T><<<grid_for(ndense, 4), 256, 0, s>>>(dense_list, ndense, vrow_off, vbase, hbits, nlong, colbits, qstage,
+                                                                              seg_nnz);
+                    res->info.dense_segments += ndense;
+                    rest_list = others;
+                    nrest = nseg_long - ndense;
+                }
+            }
+            dbg_sync(s, "over-long segments: dense accumulation");
+            // the rest by length: up to kBigTileCap -> one big LDS tile each, reduced in place; beyond -> global sort
+            // (debugging aid: OSP_BIGTILE_CAP=0 sends every such segment down the global-sort path)
             const uint32_t big_cap = getenv("OSP_BIGTILE_CAP") ? std::min<uint32_t>((uint32_t)strtoul(getenv("OSP_BIGTILE_CAP"), nullptr, 10), kBigTileCap)
                                                                 : (uint32_t)kBigTileCap;
-            const SegHugeFlag hf{p1.long_rows, vrow_off, big_cap};
-            device_exclusive_scan<SegHugeFlag, uint32_t>(hf, nseg_long, hscan, (uint32_t *)sscan_tmp, s);
-            const uint32_t nhuge = d2h(hscan + nseg_long, s), nmid = nseg_long - nhuge;
-            uint32_t *huge_list = sc.get<uint32_t>(nhuge), *mid_list = sc.get<uint32_t>(nmid);
-            seg_partition_kernel<<<grid_for(nseg_long, 256), 256, 0, s>>>(hf, hscan, nseg_long, huge_list, mid_list);
+            uint32_t nhuge = 0, nmid = 0;
+            uint32_t *huge_list = nullptr, *mid_list = nullptr;
+            if (nrest) {
+                const SegHugeFlag hf{rest_list, vrow_off, big_cap};
+                device_exclusive_scan<SegHugeFlag, uint32_t>(hf, nrest, hscan, (uint32_t *)sscan_tmp, s);
+                nhuge = d2h(hscan + nrest, s);
+                nmid = nrest - nhuge;
+                huge_list = sc.get<uint32_t>(nhuge);
+                mid_list = sc.get<uint32_t>(nmid);
+                seg_partition_kernel<<<grid_for(nrest, 256), 256, 0, s>>>(hf, hscan, nrest, huge_list, mid_list);
+            }
             res->info.sorted_segments += nhuge;
             if (nmid) {
                 TileDesc *bdesc = sc.get<TileDesc>(nmid);

@@ -202,6 +202,90 @@ __global__ void split_vrows_kernel(uint32_t nheavy, const uint64_t *vbase, const
     vrow_off[v] = hoff[h] + (goffs[hbase[h] + d * nstretch[h]] - goffs[hbase[h]]);
 }
 
+// ---- over-long segments of hub rows: dense accumulation ------------------------------------------------------------------
+// A segment that still exceeds a merge tile after the split is, in a hub row, a NARROW column range fed by thousands of
+// products: a row of U partial products is cut into up to 4096 ranges, so at Graph500 skew the range of a segment is a few
+// hundred columns while the segment holds thousands of entries (hub row x hub column).  Sorting that is the wrong tool
+// (one 4096-entry LDS tile per segment, or five global radix passes for the "piles" beyond: a fifth of the Graph500
+// product's time).  A wave takes such a segment and keeps ONE accumulator per column of its range in LDS: entries are
+// consumed 64 at a time in staging order (= ascending k); lanes that hold the same column inside one group are ranked
+// (ballot matching) and added in rank order, one round per rank, so every column's sum is formed in exactly the order the
+// sort-and-sum would use -- same bits -- and different columns proceed in parallel.  A bitmap remembers which columns
+// occurred (a sum that cancels to zero is still an entry).  The compacted (column, sum) pairs go back over the segment's
+// own beginning, like the other paths for over-long segments.
+constexpr int kDenseBits = 10;  // segments whose column range is at most 2^10 columns
+struct SegDenseFlag {
+    const uint32_t *list;   // over-long segments (virtual rows)
+    const uint64_t *vbase;  // first segment of every long row
+    const uint8_t *hbits;   // split bits of every long row
+    uint32_t nlong;
+    int colbits, enabled;
+    __device__ uint32_t operator()(uint64_t t) const {
+        if (!enabled) return 0u;
+        const uint32_t v = list[t];
+        const uint32_t h = (uint32_t)(upper_bound_dev(vbase, 0, (uint64_t)nlong + 1, (uint64_t)v) - 1);
+        return (colbits - (int)hbits[h]) <= kDenseBits ? 1u : 0u;
+    }
+};
+// list[t] -> yes[scan[t]] or no[t - scan[t]]; scan = exclusive scan of the flags
+template <class F>
+__global__ void seg_split_list_kernel(F f, const uint32_t *scan, uint32_t n, uint32_t *yes, uint32_t *no) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    if (f(t)) yes[scan[t]] = f.list[t]; else no[t - scan[t]] = f.list[t];
+}
+template <class T>
+__global__ __launch_bounds__(256) void dense_segment_kernel(const uint32_t *list, uint32_t nlist, const uint64_t *vrow_off, const uint64_t *vbase,
+                                                          const uint8_t *hbits, uint32_t nlong, int colbits, Part<T> *qstage,
+                                                          uint32_t *seg_nnz) {
+    constexpr int NW = 256 / kWave, R_MAX = 1 << kDenseBits;
+    __shared__ T acc[NW][R_MAX];
+    __shared__ uint32_t seen[NW][R_MAX / 32];
+    const unsigned lane = lane_id(), w = threadIdx.x >> 6;
+    const uint32_t idx = blockIdx.x * NW + w;
+    if (idx >= nlist) return;  // (no workgroup barrier below: the waves are independent)
+    const uint32_t v = list[idx];
+    const uint32_t h = (uint32_t)(upper_bound_dev(vbase, 0, (uint64_t)nlong + 1, (uint64_t)v) - 1);
+    const int sh = colbits - (int)hbits[h];
+    const uint32_t cbase = (uint32_t)((v - vbase[h]) << sh), R = 1u << sh;
+    const uint64_t s0 = vrow_off[v], m = vrow_off[v + 1] - s0;
+    for (uint32_t c = lane; c < R / 32 + (R < 32 ? 1u : 0u); c += kWave) seen[w][c] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    Part<T> *seg = qstage + s0;
+    for (uint64_t i0 = 0; i0 < m; i0 += kWave) {
+        const uint64_t i = i0 + lane;
+        const bool valid = i < m;
+        const PartWords<T> rec = load_part_words(&seg[valid ? i : 0]);
+        const uint32_t rel = valid ? rec.col() - cbase : 0u;
+        unsigned rk, cnt;
+        wave_match_bits(rel, sh, valid, rk, cnt);
+        // round r: the lanes whose entry is the r-th of its column inside this group -- distinct columns, no conflict
+        for (unsigned r = 0; __ballot(valid && rk >= r) != 0; r++) {
+            if (valid && rk == r) {
+                const uint32_t bit = 1u << (rel & 31u);
+                const uint32_t old = seen[w][rel >> 5];
+                // a column's sum STARTS as its first entry (0 + (-0.0) would lose the sign of a lone negative zero)
+                if (old & bit) acc[w][rel] += rec.val();
+                else { acc[w][rel] = rec.val(); atomicOr(&seen[w][rel >> 5], bit); }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // compact: columns in ascending order, back over the segment's own beginning (all of it has been consumed)
+    uint32_t out = 0;
+    for (uint32_t c0 = 0; c0 < R; c0 += kWave) {
+        const uint32_t c = c0 + lane;
+        const bool on = c < R && ((seen[w][c >> 5] >> (c & 31u)) & 1u);
+        const uint64_t mask = __ballot(on);
+        if (on) {
+            const uint32_t pos = out + (uint32_t)__popcll(mask & lanemask_lt());
+            seg[pos] = Part<T>{cbase + c, acc[w][c]};
+        }
+        out += (uint32_t)__popcll(mask);
+    }
+    if (lane == 0) seg_nnz[v] = out;
+}
+
 // One workgroup splits one long row of at most kSplitRowMax entries: histogram over its segments, scan, stable
 // scatter -- the row is read twice, the second time from cache.  No global histogram, no device-wide scan.
 // Two variants were built, measured on R-MAT-22 (28 GB of long-row records per launch, 18.6 ms as it stands) and NOT kept:

@@ -49,6 +49,9 @@ def test_random_products_match_the_oracle(ctx, port, monkeypatch, seed):
         monkeypatch.setenv("OSP_SPLIT_ROW_MAX", str(int(rng.choice([0, 3000, 20000]))))
     if seed % 6 == 2:
         monkeypatch.setenv("OSP_BIGTILE_CAP", "0")  # every over-long segment takes the global-sort path
+    if seed % 2 == 0:
+        # (the inputs here are narrow: every over-long segment would otherwise go to the dense accumulators of hub rows)
+        monkeypatch.setenv("OSP_DENSE_SEG", "0")
     acsc = S.coo_to_csc(K, a[0], a[1], a[2])
     bcsr = S.coo_to_csr(K, b[0], b[1], b[2])
     want = port.spgemm(M, K, N, *acsc, *bcsr)
@@ -71,6 +74,7 @@ def test_random_products_match_the_oracle(ctx, port, monkeypatch, seed):
     SEEN["cases"] += 1
     SEEN["long_rows"] += res.info["heavy_rows"] > 0
     SEEN["piles"] += res.info["sorted_segments"] > 0
+    SEEN["dense"] = SEEN.get("dense", 0) + (res.info["dense_segments"] > 0)
     SEEN["panels"] += res.info["panels"] > 1
     # the same product as row shards
     G = int(rng.integers(2, 5))

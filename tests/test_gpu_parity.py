@@ -126,9 +126,12 @@ def test_rmat10_golden_digest(ctx, golden_dir, dt):
     assert res.info["heavy_rows"] > 0
 
 
-def test_long_rows_split_and_fallback(ctx, port):
-    """Rows far longer than an LDS tile: split by column range; a segment that is still too long
-    (one column hit by thousands of partial products) takes the global-sort path.  Bit-exact."""
+@pytest.mark.parametrize("dense", ["1", "0"])
+def test_long_rows_split_and_fallback(ctx, port, monkeypatch, dense):
+    """Rows far longer than an LDS tile: split by column range; a segment that is still too long (one column hit by
+    thousands of partial products) is reduced by dense accumulation when its column range is narrow (hub rows), else by a
+    big in-place tile or the global-sort path (OSP_DENSE_SEG=0 sends this one there).  Bit-exact every way."""
+    monkeypatch.setenv("OSP_DENSE_SEG", dense)
     rng = np.random.default_rng(3)
     M, K, N = 8, 6000, 64
     # row 0 of A is dense in k; every B row hits column 5 plus two random columns -> column 5 of C[0,:]
@@ -142,7 +145,8 @@ def test_long_rows_split_and_fallback(ctx, port):
     b = (b_rows, b_cols, rng.uniform(0.5, 1.5, 3 * K))
     for dt in (np.float64, np.float32):
         got, want = run_both(ctx, port, M, K, N, a, b, dt)
-        assert got.info["heavy_rows"] >= 1 and got.info["sorted_segments"] >= 1
+        assert got.info["heavy_rows"] >= 1
+        assert (got.info["dense_segments"] >= 1) if dense == "1" else (got.info["sorted_segments"] >= 1 and got.info["dense_segments"] == 0)
         assert_same(got, want)
 
 
@@ -742,6 +746,7 @@ def test_ballot_rank_fallback_is_exact(port, monkeypatch):
                 assert_same(got, want)
         monkeypatch.setenv("OSP_SPLIT_ROW_MAX", "0")      # every long row through the stretch split
         monkeypatch.setenv("OSP_BIGTILE_CAP", "0")        # every over-long segment through the global sort
+        monkeypatch.setenv("OSP_DENSE_SEG", "0")          # (not the dense accumulators: they rank by ballot in any case)
         n, rows, cols, vals = gen.rmat_coo(12, 16, "g500", seed=6)
         got, want = run_both(c, port, n, n, n, (rows, cols, vals), (rows, cols, vals), np.float64)
         assert got.info["sorted_segments"] > 0
@@ -750,3 +755,43 @@ def test_ballot_rank_fallback_is_exact(port, monkeypatch):
         p = rng.permutation(len(rows))
         got = c.spgemm_coo(n, n, n, (rows[p], cols[p], vals[p]), (rows, cols, vals))
         assert_same(got, want)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_hub_segments_dense_accumulation(ctx, port, monkeypatch, dt):
+    """Over-long segments with a narrow column range -- hub row x hub columns, the Graph500 case -- are reduced by one LDS
+    accumulator per column, entries taken in staging order and equal columns of one 64-entry group added in rank order:
+    the bits of the sort-and-sum.  Cases: a row whose products pile up on a handful of columns (thousands of duplicates per
+    column), exact cancellation inside a pile (the zero stays an entry), a lone negative zero, and Graph500 skew."""
+    rng = np.random.default_rng(17)
+    M, K, N = 4, 9000, 512
+    # row 0 of A is dense in k; every B row has three entries among 12 hub columns + one elsewhere
+    a = (np.zeros(K, np.uint32), np.arange(K, dtype=np.uint32), rng.uniform(0.5, 1.5, K).astype(dt))
+    hub = rng.integers(0, 12, (K, 3))
+    hub.sort(axis=1)
+    cols = np.concatenate([hub, rng.integers(12, N, (K, 1))], 1)
+    keep = np.ones(cols.shape, bool)
+    keep[:, 1:3] = cols[:, 1:3] != cols[:, 0:2]
+    b_rows = np.repeat(np.arange(K, dtype=np.uint32), 4)[keep.reshape(-1)]
+    b_cols = cols.reshape(-1)[keep.reshape(-1)].astype(np.uint32)
+    b_vals = rng.uniform(-1.0, 1.0, len(b_cols)).astype(dt)
+    # exact cancellation on column 3: the entries of the first two B rows that hit it cancel, nothing else hits it
+    sel3 = b_cols == 3
+    b_vals[sel3] = 0.0
+    first = np.flatnonzero(sel3)[:2]
+    a_k = a[2][b_rows[first]]
+    b_vals[first[0]] = 1.0 / a_k[0].astype(np.float64) if False else dt(1.0)
+    b_vals[first[1]] = dt(-(a_k[0] * dt(1.0)) / a_k[1])
+    got, want = run_both(ctx, port, M, K, N, a, (b_rows, b_cols, b_vals), dt)
+    assert got.info["dense_segments"] >= 1 and got.info["sorted_segments"] == 0
+    assert_same(got, want)
+    # a lone negative zero in a pile of zeros keeps its sign only if the sum starts AS the first entry
+    b2 = (np.arange(K, dtype=np.uint32), np.zeros(K, np.uint32), np.zeros(K, dt))
+    b2[2][0] = dt(-0.0)
+    got, want = run_both(ctx, port, M, K, N, (a[0], a[1], np.ones(K, dt)), b2, dt)
+    assert_same(got, want)
+    assert np.signbit(got.vals[0]) == np.signbit(want["vals"][0])
+    # Graph500 skew at a size the oracle still handles
+    n, rows, cols_, vals = gen.rmat_coo(14, 16, "g500", seed=2, dtype=dt)
+    got, want = run_both(ctx, port, n, n, n, (rows, cols_, vals), (rows, cols_, vals), dt)
+    assert_same(got, want)
