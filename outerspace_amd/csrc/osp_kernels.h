@@ -38,6 +38,11 @@ constexpr int kMulPerBlock = kMulPerWave * (kMulThreads / kWave);
 #endif
 constexpr int kMulBatchMax = OSP_MUL_BATCH_MAX;  // up to 64 consecutive columns with at most this many products are one batch
 constexpr int kMulBatchAvg = 64;  // ... and at most this many per column on average
+#ifndef OSP_MUL_TILE_MIN
+#define OSP_MUL_TILE_MIN 1024
+#endif
+constexpr int kMulTileMin = OSP_MUL_TILE_MIN;  // B rows from this length on: products numbered in panels of the row (multiply_kernel)
+constexpr int kMulTileW = 128;                 // ... of this many entries
 
 // One staged partial product: 4-byte column + value, packed (12 B for f64, 8 B for f32).  Array of
 // records rather than two arrays: a chunk is then ONE contiguous byte range, which halves the number
@@ -332,7 +337,58 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
             j0 = a / nb; la = a - j0 * nb;
             j1 = (b - 1) / nb; lb = b - j1 * nb;
         }
-        if (nb > 32) {
+        if (nb >= (uint32_t)kMulTileMin) {
+            // A long B row (a hub column's row at Graph500 skew holds 10^5 entries): numbered j-major, a wave's slice is a
+            // piece of ONE chunk, so every product costs a 12-byte read of B beside its 12-byte write, each window of the row
+            // fetched again by every wave that passes it.  The products of such a column are numbered in PANELS of
+            // kMulTileW entries of the B row instead -- panel, then A entry, then entry inside the panel -- so that a slice
+            // covers one window of the row for several A entries: the window is loaded once into registers (four entries
+            // per lane) and written to every chunk of the slice.  Which wave writes a product changes, not where it goes.
+            constexpr uint32_t W = (uint32_t)kMulTileW, PER = W / kWave;
+            const uint64_t full = (uint64_t)a_cnt[kk] * W;   // products of a whole panel
+            const uint32_t npanel = (nb + W - 1) / W;
+            for (uint64_t x = a; x < b;) {
+                const uint32_t pnl = (uint32_t)min(x / full, (uint64_t)npanel - 1);
+                const uint32_t wp = pnl == npanel - 1 ? nb - pnl * W : W;
+                const uint64_t pbeg = (uint64_t)pnl * full;
+                const uint64_t xe = min(b, pbeg + (uint64_t)a_cnt[kk] * wp) - pbeg, xin = x - pbeg;
+                const uint64_t tj0 = xin / wp, tj1 = (xe - 1) / wp;
+                const uint32_t tla = (uint32_t)(xin - tj0 * wp), tlb = (uint32_t)(xe - tj1 * wp);
+                uint32_t bc[PER];
+                T bv[PER];
+#pragma unroll
+                for (uint32_t u = 0; u < PER; u++) {
+                    const uint32_t lrel = u * kWave + lane;
+                    const uint64_t src = bs + (uint64_t)pnl * W + min(lrel, wp - 1);   // clamped: the loads go out together
+                    bc[u] = b_colidx[src];
+                    bv[u] = b_vals[src];
+                }
+                for (uint64_t jb = tj0; jb <= tj1; jb += kWave) {
+                    const uint64_t jm = jb + lane;
+                    T av_l = 0;
+                    uint64_t off_l = kChunkSkip;
+                    if (jm <= tj1) {
+                        av_l = a_vals[as + jm];
+                        const uint64_t raw = chunk_off[as + jm - (uint64_t)e0];
+                        off_l = raw == kChunkSkip ? kChunkSkip : raw - base + (uint64_t)pnl * W;
+                    }
+                    const uint32_t cj = (uint32_t)min((uint64_t)kWave, tj1 - jb + 1);
+                    for (uint32_t q = 0; q < cj; q++) {
+                        const uint64_t j = jb + q;
+                        const T av = wave_bcast(av_l, q);
+                        const uint64_t off = wave_bcast(off_l, q);
+                        if (off == kChunkSkip) continue;
+                        const uint32_t lo = j == tj0 ? tla : 0u, hi = j == tj1 ? tlb : wp;
+#pragma unroll
+                        for (uint32_t u = 0; u < PER; u++) {
+                            const uint32_t lrel = u * kWave + lane;
+                            if (lrel >= lo && lrel < hi) stream_store_part(&stage[off + lrel], bc[u], av * bv[u]);
+                        }
+                    }
+                }
+                x = pbeg + xe;
+            }
+        } else if (nb > 32) {
             // A entries in batches of 64: lane q fetches entry jb+q's value and chunk offset once, the inner loop
             // reads them with v_readlane -- no dependent global load per chunk
             for (uint64_t jb = j0; jb <= j1; jb += kWave) {
