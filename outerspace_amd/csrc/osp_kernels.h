@@ -497,6 +497,16 @@ __global__ void compact_flagged_kernel(F f, const uint32_t *scan, uint64_t n, ui
 // rows are written ONCE, straight to c_col / c_val / c_rowptr (no per-row compaction pass).
 constexpr uint64_t kStatusAgg = 1ull << 62, kStatusPrefix = 2ull << 62, kStatusMask = (1ull << 62) - 1;
 
+#ifndef OSP_RUN_SHORT
+#define OSP_RUN_SHORT 8
+#endif
+constexpr int kRunShort = OSP_RUN_SHORT;  // entries of a run its head thread sums itself; the rest of a longer run: a wave (merge_tiles_kernel)
+template <class T> __device__ __forceinline__ T index_as_value(uint32_t i);
+template <> __device__ __forceinline__ float index_as_value<float>(uint32_t i) { return __uint_as_float(i); }
+template <> __device__ __forceinline__ double index_as_value<double>(uint32_t i) { return __longlong_as_double((long long)i); }
+__device__ __forceinline__ uint32_t value_as_index_impl(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ uint32_t value_as_index_impl(double v) { return (uint32_t)__double_as_longlong(v); }
+template <class T> __device__ __forceinline__ uint32_t value_as_index(T v) { return value_as_index_impl(v); }
 #ifndef OSP_DIGIT_BITS
 #define OSP_DIGIT_BITS 10
 #endif
@@ -526,7 +536,7 @@ struct alignas(8) MergeSmem {
     };
     uint32_t rowo[kTileMaxRows + 1];
     uint32_t scratch[NT / kWave + 1];
-    uint32_t tile;
+    uint32_t nlongrun;  // runs longer than kRunShort, summed by whole waves (their positions and sums: behind `rank`)
     uint32_t hcount;  // distinct (row, col) keys of the tile, counted by hashing before the sort
     uint64_t excl;
     __device__ __forceinline__ uint32_t *key(int c) { return c ? key1 : key0; }
@@ -534,6 +544,12 @@ struct alignas(8) MergeSmem {
     // where the values go once the sorted keys sit in buffer `c`
     __device__ __forceinline__ T *vals(int c) { return reinterpret_cast<T *>(c ? reinterpret_cast<char *>(key0) : reinterpret_cast<char *>(pad)); }
     __device__ __forceinline__ uint32_t *htab() { return reinterpret_cast<uint32_t *>(pos0); }
+    // long runs: the part of the dead digit counters that `rank` leaves free
+    static constexpr int kMaxLong = CAP / kRunShort;
+    static constexpr size_t kLongOff = ((CAP + 1) * sizeof(uint16_t) + 7) / 8 * 8;
+    static_assert(kLongOff + kMaxLong * (sizeof(T) + sizeof(uint16_t)) <= sizeof(uint16_t) * (NT / kWave) * kDigits, "long-run list: behind rank, inside the counters");
+    __device__ __forceinline__ T *long_sum() { return reinterpret_cast<T *>(reinterpret_cast<char *>(cnt) + kLongOff); }
+    __device__ __forceinline__ uint16_t *long_pos() { return reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(cnt) + kLongOff + kMaxLong * sizeof(T)); }
 };
 
 // Rank of this lane among the lanes of its wave that hold the same digit (lower lanes first), and
@@ -1203,6 +1219,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                 if (i < n) sval[i] = vq[q];
             }
         }
+        if (tid == 0) sm.nlongrun = 0;  // (the scan's barrier orders this before the run sums)
         uint32_t total;
         uint32_t ex = block_excl_scan<uint32_t, NT, false>(heads, sm.scratch, &total);  // (the next scan is barriers away)
         OSP_PROF_MARK(6);
@@ -1231,8 +1248,11 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
         }
         if (tid == 0) sm.rank[n] = (uint16_t)total;
         // each head sums its run in staging order (= ascending k)
+        // A head walks at most kRunShort entries itself.  A longer run (a hub column: at Graph500 skew one output entry of a
+        // tile is fed by hundreds of products) would keep ONE lane busy for three dependent LDS round trips per entry while
+        // the rest of the workgroup waits; it is handed, with the sum so far, to a whole wave below.
         T acc[IPT];
-        uint32_t ocol[IPT];
+        uint32_t ocol[IPT], lmask = 0;
 #pragma unroll
         for (int q = 0; q < IPT; q++) {
             const uint32_t i = ib + q;
@@ -1240,20 +1260,53 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
             if (i < n && ((hmask >> q) & 1u)) {
                 const uint32_t k = skey[i];
                 T a = sval[spos[i]];
-                for (uint32_t u = i + 1; u < n && skey[u] == k; u++) a += sval[spos[u]];
+                const uint32_t ulim = min(n, i + (uint32_t)kRunShort);
+                uint32_t u = i + 1;
+                for (; u < ulim && skey[u] == k; u++) a += sval[spos[u]];
+                if (u == ulim && u < n && skey[u] == k) {
+                    const uint32_t idx = atomicAdd(&sm.nlongrun, 1u);
+                    sm.long_sum()[idx] = a;
+                    sm.long_pos()[idx] = (uint16_t)u;
+                    lmask |= 1u << q;
+                    a = index_as_value<T>(idx);
+                }
                 acc[q] = a;
                 ocol[q] = relkey ? k + cbase : (k & colmask);
             }
         }
         if (tid == 0) s_tnext = tn_reg;
         __syncthreads();  // all gathers from the keys / values done; sm.excl and s_tnext are published
+        if (const uint32_t nlr = sm.nlongrun) {
+            // the long runs, one per wave at a time: 64 values per LDS round trip, then added one by one IN ORDER (the sum
+            // is the same left-to-right chain of additions, only fed from registers)
+            T *lsum = sm.long_sum();
+            const uint16_t *lpos = sm.long_pos();
+            for (uint32_t r = w; r < nlr; r += NW) {
+                const uint32_t u1 = lpos[r], k = skey[u1];
+                T a = lsum[r];
+                for (uint32_t u0 = u1;; u0 += kWave) {
+                    const uint32_t u = u0 + lane;
+                    const bool in = u < n && skey[u] == k;
+                    const T v = in ? sval[spos[u]] : T(0);
+                    const uint64_t m = __ballot(in);
+                    const uint32_t c = m == ~0ull ? (uint32_t)kWave : (uint32_t)__builtin_ctzll(~m);  // the run is contiguous
+                    for (uint32_t x = 0; x < c; x++) a += wave_bcast(v, x);
+                    if (c < (uint32_t)kWave) break;
+                }
+                if (lane == 0) lsum[r] = a;
+            }
+            __syncthreads();  // before the compaction overwrites what the waves are still reading
+        }
         OSP_PROF_MARK(8);
         // compact in LDS (columns over the sorted keys, sums over the values), then stream out with consecutive
         // lanes on consecutive addresses
 #pragma unroll
         for (int q = 0; q < IPT; q++) {
             const uint32_t i = ib + q;
-            if (i < n && ((hmask >> q) & 1u)) { skey[oslot[q]] = ocol[q]; sval[oslot[q]] = acc[q]; }
+            if (i < n && ((hmask >> q) & 1u)) {
+                skey[oslot[q]] = ocol[q];
+                sval[oslot[q]] = ((lmask >> q) & 1u) ? sm.long_sum()[value_as_index<T>(acc[q])] : acc[q];
+            }
         }
         if (tid == 0 && tn_reg < ntiles) s_dnext = desc[tn_reg];
         __syncthreads();

@@ -705,14 +705,19 @@ def test_rmat22_full_size_properties_and_slab_parity(ctx, port):
     del got_rowsum, want_rowsum, b1
     # ---- linearity, streamed: (2A) * B == 2 * C exactly, panel by panel against the resident result ----
     a2 = csc[2] * 2.0
+    torch.cuda.synchronize()   # the library runs on its own stream
     seen = {"rows": 0, "nnz": 0}
 
     def on_panel(p):
         lo = int(rowptr[p["row_begin"]])
         nr = p["row_end"] - p["row_begin"]
-        assert p["nnz"] == int(rowptr[p["row_end"]]) - lo
         prp = _as_tensor(p["rowptr"], nr + 1, "<i8", dev, torch.int64)
-        assert torch.equal(prp, rowptr[p["row_begin"]:p["row_end"] + 1] - lo)
+        ref = rowptr[p["row_begin"]:p["row_end"] + 1] - lo
+        if not torch.equal(prp, ref):   # say where: the first row whose entry count differs
+            r = int(torch.nonzero(prp != ref)[0]) - 1
+            raise AssertionError(f"panel {p['index']} rows [{p['row_begin']},{p['row_end']}): row {p['row_begin'] + r} holds "
+                                 f"{int(prp[r + 1] - prp[r])} entries, resident product {int(ref[r + 1] - ref[r])}")
+        assert p["nnz"] == int(rowptr[p["row_end"]]) - lo
         note(f"panel {p['index'] + 1} of {p['count']}")
         for s0 in range(0, p["nnz"], CH):
             s1 = min(s0 + CH, p["nnz"])
@@ -754,6 +759,41 @@ def test_ballot_rank_fallback_is_exact(port, monkeypatch):
         rng = np.random.default_rng(3)
         p = rng.permutation(len(rows))
         got = c.spgemm_coo(n, n, n, (rows[p], cols[p], vals[p]), (rows, cols, vals))
+        assert_same(got, want)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_long_runs_inside_tiles(ctx, port, dt):
+    """Runs longer than kRunShort inside ordinary tiles (an output entry fed by dozens to hundreds of products) are summed by
+    a whole wave, 64 values per round trip, added one by one in staging order: the bits of the one-lane walk.  Rows that fit
+    a tile (level 0), rows that are split (segment tiles), runs that end exactly at the 8th / 64th entry and at the tile's
+    end."""
+    rng = np.random.default_rng(23)
+    M, K, N = 96, 700, 4096
+    rows, cols = [], []
+    for i in range(M):
+        nk = 250 if i % 2 == 0 else 650   # ~900 products (one tile) or ~2300 (split into segments)
+        ks = np.sort(rng.choice(K, nk, replace=False))
+        rows.append(np.full(nk, i)); cols.append(ks)
+    a_rows = np.concatenate(rows).astype(np.uint32); a_cols = np.concatenate(cols).astype(np.uint32)
+    a = (a_rows, a_cols, rng.uniform(-1.0, 1.0, len(a_rows)).astype(dt))
+    # every B row: column 7 always (runs of 250 / 650), one of 16 hub columns (runs of ~15 / ~40), two anywhere
+    hub = 100 + 37 * rng.integers(0, 16, K)
+    anyc = rng.integers(2000, N, (K, 2))
+    cols = np.concatenate([np.full((K, 1), 7), hub[:, None], anyc], 1)
+    cols.sort(axis=1)
+    keep = np.ones(cols.shape, bool)
+    keep[:, 1:] = cols[:, 1:] != cols[:, :-1]
+    b_rows = np.repeat(np.arange(K, dtype=np.uint32), 4)[keep.reshape(-1)]
+    b_cols = cols.reshape(-1)[keep.reshape(-1)].astype(np.uint32)
+    b = (b_rows, b_cols, rng.uniform(-1.0, 1.0, len(b_cols)).astype(dt))
+    got, want = run_both(ctx, port, M, K, N, a, b, dt)
+    assert_same(got, want)
+    # runs of exactly 8, 9, 64, 65 and 72 products, and one that fills a whole tile's worth of a row
+    for L in (8, 9, 64, 65, 72, 1500):
+        a1 = (np.zeros(L, np.uint32), np.arange(L, dtype=np.uint32), rng.uniform(-1.0, 1.0, L).astype(dt))
+        b1 = (np.arange(L, dtype=np.uint32), np.full(L, 3, np.uint32), rng.uniform(-1.0, 1.0, L).astype(dt))
+        got, want = run_both(ctx, port, 2, L, 16, a1, b1, dt)
         assert_same(got, want)
 
 
