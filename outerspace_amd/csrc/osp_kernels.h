@@ -283,7 +283,11 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
             // lane q: products of columns [kk, kk+q] -- the batch is the longest prefix that stays within the limit, so a
             // hub column ends a batch instead of spoiling it
             const uint64_t pe = prod_off[min(kk + lane + 1, nk)] - p0;
-            const uint64_t fits = __ballot(kk + lane < nk && pe <= (uint64_t)kMulBatchMax);
+            // (a column whose B row is numbered in panels -- below -- never joins a batch: the waves that share a column
+            // must agree on the numbering of its products, and the batch walk numbers them chunk by chunk)
+            const uint64_t bs_l = (uint64_t)b_rowptr[k0 + min(kk + lane, nk - 1)];
+            const uint32_t nb_l = (uint32_t)((uint64_t)b_rowptr[k0 + min(kk + lane, nk - 1) + 1] - bs_l);
+            const uint64_t fits = __ballot(kk + lane < nk && pe <= (uint64_t)kMulBatchMax && nb_l < (uint32_t)kMulTileMin);
             const uint32_t ncol = fits == ~0ull ? (uint32_t)kWave : (uint32_t)__builtin_ctzll(~fits);  // pe ascends: a prefix of lanes
             // (and only where the columns are small on average: with B's row in registers the per-column path below is the
             // faster one from about 64 products per column on -- uniform R-MAT measured 9.0 against 9.8 ms)
@@ -294,8 +298,8 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                 const bool cv = kq < kend;
                 const uint32_t prev = (uint32_t)__shfl_up((int)(uint32_t)min(pe, (uint64_t)0x7fffffffu), 1);
                 const uint32_t rel0 = cv ? (lane ? prev : 0u) : (uint32_t)(pend - p0);  // lanes past the end: behind all
-                const uint64_t bsq = cv ? (uint64_t)b_rowptr[k0 + kq] : 0ull;
-                const uint32_t nbq = cv ? (uint32_t)((uint64_t)b_rowptr[k0 + kq + 1] - bsq) : 1u;
+                const uint64_t bsq = cv ? bs_l : 0ull;
+                const uint32_t nbq = cv ? nb_l : 1u;
                 const uint64_t asq = cv ? (uint64_t)a_start[kq] : 0ull;
                 const uint32_t lo_p = (uint32_t)(cur - p0), hi_p = (uint32_t)(min(we, pend) - p0);
                 for (uint32_t x0 = lo_p; x0 < hi_p; x0 += kWave) {
