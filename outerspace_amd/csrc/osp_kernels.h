@@ -601,14 +601,24 @@ __global__ __launch_bounds__(256) void rank_order_selftest_kernel(uint32_t *bad)
     if (nbad) atomicAdd(bad, nbad);
 }
 
-// (Tickets: the persistent workgroups of merge_tiles_kernel take their tiles from ONE counter word.  A word serves about 88
-// returning atomics per microsecond on MI355X whoever asks (/opt/skills/guides/MI355X_MICROARCH.md, price list, "dequeue"),
-// and the kernel hands out 68-76 tiles per microsecond: the counter is at ~80 % of what it can give, and with everything
-// but load, sort and store switched off tools/bench_merge runs at exactly that bound (2.19 ms for 174 763 tiles).  A
-// two-level dispenser -- eight group words holding chunks of 32 tickets claimed on demand from a global counter -- was
-// built and measured: correct for every grid size, and much SLOWER (4.0 against 2.36 ms): 160 workgroups per group drain
-// a chunk faster than its refill's two dependent atomics come back.  Interleaved per-group counters would lift the bound
-// but can deadlock when a whole group of workgroups is not resident; not done.)
+// (Tickets: the persistent workgroups of merge_tiles_kernel take their tiles from ONE counter word, and that word is what
+// bounds the kernel today.  A word serves about 88 returning atomics per microsecond on MI355X whoever asks
+// (/opt/skills/guides/MI355X_MICROARCH.md, price list, "dequeue"); the kernel hands out 68-76 tiles per microsecond, and
+// tools/bench_merge with the sort AND the look-back switched off still takes 2.19 ms for 174 763 tiles (80 per
+// microsecond) -- while the same kernel with tiles assigned statically (no ticket, no look-back) SORTS them in 1.79 ms, and
+// loads, hashes and stores them in 1.31.  What was tried to lift the bound, all measured on those tiles (2.40 ms as is):
+//   * static assignment with the look-back: 3.03 ms -- a slow workgroup stalls everything behind it;
+//   * a two-level dispenser -- eight group words holding chunks of 32 tickets claimed on demand from a global counter:
+//     correct for every grid size, 4.0 ms -- 160 workgroups per group drain a chunk faster than its refill's two dependent
+//     atomics come back;
+//   * the same in-order sequence spread over 4 or 8 words (word w hands out tiles w, w+W, ...; a workgroup reads all the
+//     words and increments the one whose next tile is smallest, which keeps the guarantee that the smallest tile nobody
+//     holds is what the next free workgroup takes): correct for every grid size, 6.3 / 5.8 ms -- the reads of the hot
+//     counter lines cost what the atomics cost, and there are W of them per ticket;
+//   * words bound to groups of workgroups (no reads) would lift it, but a tile could then wait for a tile that only a
+//     workgroup not yet resident can take: with two processes on one device that is a deadlock; not done.
+// What is left is fewer, larger tiles -- LDS per entry is what limits that (five workgroups of 1536 entries per CU beat
+// four of 2048, see TileCap).)
 // Exclusive prefix of tile `t` by decoupled look-back (called by wave 0 of the block).
 // One round trip fetches kLookWin windows of 64 predecessors.  (Measured: wide windows lose -- the
 // extra polling traffic costs more than the walk saves -- so kLookWin = 1; what matters is that tiles

@@ -16,6 +16,10 @@
 namespace osp {
 
 constexpr int kSplitThreads = 256;
+#ifndef OSP_SPLIT_ROW_STRETCH
+#define OSP_SPLIT_ROW_STRETCH 4096
+#endif
+constexpr int kSplitRowStretch = OSP_SPLIT_ROW_STRETCH;  // ... of split_row_kernel (one workgroup per row)
 constexpr int kSplitStretch = 4096;   // entries a workgroup holds in registers at a time (one round)
 #ifndef OSP_SPLIT_JOB_ROUNDS
 #define OSP_SPLIT_JOB_ROUNDS 8
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
     const uint64_t *hoff, const uint64_t *row_off, uint64_t base, int colbits, const Part<T> *stage, Part<T> *qstage,
     uint64_t *vrow_off) {
     constexpr int NW = kSplitThreads / kWave;
-    constexpr int ITERS = kSplitStretch / kSplitThreads;
+    constexpr int ITERS = kSplitRowStretch / kSplitThreads;
     constexpr int NSEG = 1 << kSplitRowBits;
     static_assert(NSEG <= kSplitThreads, "one thread per segment in the scan");
     __shared__ alignas(8) uint16_t cnt[NW + 1][NSEG];
@@ -324,14 +328,14 @@ __global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
         if (threadIdx.x < nseg) { segoff[threadIdx.x] = ex; vrow_off[vbase[h] + threadIdx.x] = qbase + ex; }
     }
     __syncthreads();
-    for (uint64_t sb = beg; sb < end; sb += kSplitStretch) {
-        const uint64_t se = min(sb + (uint64_t)kSplitStretch, end);
+    for (uint64_t sb = beg; sb < end; sb += kSplitRowStretch) {
+        const uint64_t se = min(sb + (uint64_t)kSplitRowStretch, end);
         for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) {
 #pragma unroll
             for (int ww = 0; ww < NW; ww++) cnt[ww][d] = 0;
         }
         __syncthreads();  // also orders the segoff update of the previous round before this round's scatter
-        const uint64_t wbeg = sb + (uint64_t)w * (kSplitStretch / NW);
+        const uint64_t wbeg = sb + (uint64_t)w * (kSplitRowStretch / NW);
         uint32_t rk[ITERS];
         PartWords<T> rec[ITERS];
 #pragma unroll
