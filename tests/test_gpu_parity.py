@@ -762,29 +762,30 @@ def test_ballot_rank_fallback_is_exact(port, monkeypatch):
         assert_same(got, want)
 
 
-@pytest.mark.parametrize("preset,scale", [("mild", 19), ("g500", 16)])
-def test_panel_boundaries_sweep(ctx, preset, scale):
+@pytest.mark.parametrize("preset,scale,dt", [("mild", 19, np.float64), ("g500", 16, np.float64), ("mild", 17, np.float32)])
+def test_panel_boundaries_sweep(ctx, preset, scale, dt):
     """Where the row panels are cut depends on the staging capacity (by default: on the free memory of the moment), and
     every cut moves the wave slices of the multiply, the tiles and the long-row splits.  A hundred capacities, resident and
     streamed: every one must give the bits of the one-panel product."""
     import torch
     from outerspace_amd.distributed import _as_tensor
     dev = torch.device("cuda", 0)
-    n, csr, csc = _bench_module().rmat_device(scale, 16, gen.RMAT_PRESETS[preset], 5, dev, torch.float64)
+    n, csr, csc = _bench_module().rmat_device(scale, 16, gen.RMAT_PRESETS[preset], 5, dev, torch.float64 if dt == np.float64 else torch.float32)
     torch.cuda.synchronize()
+    fdt, tdt, idt = ("<f8", torch.float64, torch.int64) if dt == np.float64 else ("<f4", torch.float32, torch.int32)
     ptrs = [t.data_ptr() for t in (*csc, *csr)]
-    ref = ctx.spgemm_csc_csr_device(np.float64, n, n, n, ptrs)
+    ref = ctx.spgemm_csc_csr_device(dt, n, n, n, ptrs)
     P, nnz = ref.info["partials"], ref.nnz
     assert ref.info["panels"] == 1
     rp, ci, va = ref.device_ptrs()
     rowptr, colidx, vals = (_as_tensor(rp, n + 1, "<i8", dev, torch.int64), _as_tensor(ci, nnz, "<i4", dev, torch.int32),
-                            _as_tensor(va, nnz, "<f8", dev, torch.float64))
+                            _as_tensor(va, nnz, fdt, dev, tdt))
     rng = np.random.default_rng(99)
     for it in range(100):
         cap = int(rng.integers(P // 14, P // 2))
         if it % 2 == 0:
             try:
-                res = ctx.spgemm_csc_csr_device(np.float64, n, n, n, ptrs, partial_capacity=cap)
+                res = ctx.spgemm_csc_csr_device(dt, n, n, n, ptrs, partial_capacity=cap)
             except RuntimeError as e:   # a hub row alone can exceed a small capacity: that is an error by contract
                 assert "staging capacity" in str(e)
                 continue
@@ -792,7 +793,7 @@ def test_panel_boundaries_sweep(ctx, preset, scale):
             r2, c2, v2 = res.device_ptrs()
             assert torch.equal(_as_tensor(r2, n + 1, "<i8", dev, torch.int64), rowptr), cap
             assert torch.equal(_as_tensor(c2, nnz, "<i4", dev, torch.int32), colidx), cap
-            assert torch.equal(_as_tensor(v2, nnz, "<f8", dev, torch.float64).view(torch.int64), vals.view(torch.int64)), cap
+            assert torch.equal(_as_tensor(v2, nnz, fdt, dev, tdt).view(idt), vals.view(idt)), cap
             res.close()
         else:
             def on_panel(p):
@@ -803,10 +804,10 @@ def test_panel_boundaries_sweep(ctx, preset, scale):
                 assert p["nnz"] == int(rowptr[p["row_end"]]) - lo, (cap, p["index"])
                 if p["nnz"]:
                     assert torch.equal(_as_tensor(p["colidx"], p["nnz"], "<i4", dev, torch.int32), colidx[lo:lo + p["nnz"]]), (cap, p["index"])
-                    assert torch.equal(_as_tensor(p["vals"], p["nnz"], "<f8", dev, torch.float64).view(torch.int64),
-                                       vals[lo:lo + p["nnz"]].view(torch.int64)), (cap, p["index"])
+                    assert torch.equal(_as_tensor(p["vals"], p["nnz"], fdt, dev, tdt).view(idt),
+                                       vals[lo:lo + p["nnz"]].view(idt)), (cap, p["index"])
             try:
-                info = ctx.spgemm_csc_csr_panels(np.float64, n, n, n, ptrs, on_panel, partial_capacity=cap)
+                info = ctx.spgemm_csc_csr_panels(dt, n, n, n, ptrs, on_panel, partial_capacity=cap)
             except RuntimeError as e:
                 assert "staging capacity" in str(e)
                 continue
