@@ -277,9 +277,9 @@ def test_mlp_layer_full_shape_f32(ctx, port, golden_dir, H):
     assert out.nnz == int((out.toarray() != 0).sum())   # ReLU re-sparsified: no explicit zeros kept
 
 
-def test_properties_at_scale(ctx):
-    """Size-independent checks on a product too large for the oracle in seconds:
-    sorted unique columns, row sums (C*1 == A*(B*1)), and linearity in A's values."""
+def test_properties_at_scale(ctx, port):
+    """Size-independent checks (the ones the full-size tests rely on), here at a size where the oracle can confirm them:
+    sorted unique columns, row sums (C*1 == A*(B*1)), linearity in A's values -- and the oracle's bits."""
     import scipy.sparse as sp
     from outerspace_amd import spgemm as S
     n, rows, cols, vals = gen.rmat_coo(16, 16, "mild", seed=7)
@@ -301,6 +301,7 @@ def test_properties_at_scale(ctx):
     assert res.nnz == (A @ A).nnz  # values are positive: no cancellation, scipy structure agrees
     res2 = ctx.spgemm_csc_csr(n, n, n, acsc[0], acsc[1], 2.0 * acsc[2], *bcsr)
     assert np.array_equal(res2.colidx, ci) and np.array_equal(res2.vals, 2.0 * cv)
+    assert_same(res, port.spgemm(n, n, n, *acsc, *bcsr))
 
 
 def test_cli_reference_call_shape(golden_dir, tmp_path):
@@ -345,9 +346,9 @@ def test_device_pointer_api_with_torch(ctx, port):
     assert np.array_equal(got_rp, want["rowptr"]) and np.array_equal(got_ci, want["colidx"]) and np.array_equal(got_va, want["vals"])
 
 
-def test_power_law_web_graph_shape(ctx):
+def test_power_law_web_graph_shape(ctx, port):
     """BASELINE configs[1] shape (web-Google-like: power-law degrees, pattern values = 1.0), reduced size,
-    against scipy: structure exact, values exact (small integers in f64)."""
+    against the oracle (bit-exact) and scipy: structure exact, values exact (small integers in f64)."""
     import scipy.sparse as sp
     from outerspace_amd import spgemm as S
     rng = np.random.default_rng(5)
@@ -358,7 +359,9 @@ def test_power_law_web_graph_shape(ctx):
     key = np.unique(rows * n + cols)
     rows, cols = (key // n).astype(np.uint32), (key % n).astype(np.uint32)
     vals = np.ones(len(key))                                             # pattern file -> 1.0 (SimSpGEMM.cpp:92-93)
-    res = ctx.spgemm_csc_csr(n, n, n, *S.coo_to_csc(n, rows, cols, vals), *S.coo_to_csr(n, rows, cols, vals))
+    acsc, bcsr = S.coo_to_csc(n, rows, cols, vals), S.coo_to_csr(n, rows, cols, vals)
+    res = ctx.spgemm_csc_csr(n, n, n, *acsc, *bcsr)
+    assert_same(res, port.spgemm(n, n, n, *acsc, *bcsr))
     A = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
     want = (A @ A).tocsr()
     want.sort_indices()
