@@ -560,7 +560,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         uint8_t *vfirst = sc.get<uint8_t>(nvirt + 1);
         // rows up to kSplitRowMax: one workgroup each (histogram, scan and scatter in one kernel)
         tm.begin(PH_SPLIT_K);
-        OSP_WITH_RA(ctx, split_row_kernel<T, RA><<<nlong, kSplitThreads, 0, s>>>(p0.long_rows, nlong, hbits, nstretch, vbase, hoff, io.row_off,
+        OSP_WITH_RA(ctx, split_row_kernel<T, RA><<<nlong, kSplitRowThreads, 0, s>>>(p0.long_rows, nlong, hbits, nstretch, vbase, hoff, io.row_off,
                                                                                  base, colbits, io.stage, qstage, vrow_off));
         tm.end(PH_SPLIT_K);
         res->info.split_launches++;

@@ -16,6 +16,10 @@
 namespace osp {
 
 constexpr int kSplitThreads = 256;
+#ifndef OSP_SPLIT_ROW_THREADS
+#define OSP_SPLIT_ROW_THREADS 1024
+#endif
+constexpr int kSplitRowThreads = OSP_SPLIT_ROW_THREADS;  // split_row_kernel's workgroup: 16 waves on one row (see the notes at the kernel)
 #ifndef OSP_SPLIT_ROW_STRETCH
 #define OSP_SPLIT_ROW_STRETCH 4096
 #endif
@@ -297,16 +301,22 @@ __global__ __launch_bounds__(256) void dense_segment_kernel(const uint32_t *list
 //     of the histogram pass: 17.4 ms, but 4 ms per product to build the table -- the histogram pass costs hardly more than
 //     a millisecond of the kernel, because it leaves the row in cache for the scatter pass;
 //   * the scatter staged through LDS (a round's records put in segment order inside the workgroup, then streamed out with
-//     consecutive threads on consecutive records): 18.9 ms -- the direct 12-byte stores are not what limits it.
+//     consecutive threads on consecutive records): 18.9 ms -- the direct 12-byte stores are not what limits it;
+//   * more waves per CU (workgroups of 256 threads holding 2048 / 1024 entries per round: 62 / 42 registers, 8 waves per
+//     SIMD): 20.0 / 21.0 ms -- SLOWER.  The kernel waits on memory (78 % of its wave cycles parked, 6 % issuing), but what
+//     it waits for is the second read of rows that more rows in flight have pushed out of L2 (FETCH_SIZE: every row read
+//     twice).  Hence the opposite: FEWER rows in flight, each finished sooner -- workgroups of 1024 threads (4 records per
+//     thread and round): 17.0 ms; 512 threads 17.7; one such workgroup per CU instead of two 16.8 (not kept: within noise);
+//     rounds of 8192 / 16384 entries with 1024 threads 21.5.
 template <class T, bool RA>
-__global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
+__global__ __launch_bounds__(kSplitRowThreads) void split_row_kernel(
     const uint32_t *rows, uint32_t nheavy, const uint8_t *hbits, const uint32_t *nstretch, const uint64_t *vbase,
     const uint64_t *hoff, const uint64_t *row_off, uint64_t base, int colbits, const Part<T> *stage, Part<T> *qstage,
     uint64_t *vrow_off) {
-    constexpr int NW = kSplitThreads / kWave;
-    constexpr int ITERS = kSplitRowStretch / kSplitThreads;
+    constexpr int NW = kSplitRowThreads / kWave;
+    constexpr int ITERS = kSplitRowStretch / kSplitRowThreads;
     constexpr int NSEG = 1 << kSplitRowBits;
-    static_assert(NSEG <= kSplitThreads, "one thread per segment in the scan");
+    static_assert(NSEG <= kSplitRowThreads, "one thread per segment in the scan");
     __shared__ alignas(8) uint16_t cnt[NW + 1][NSEG];
     __shared__ uint32_t segoff[NSEG];  // histogram, then running offset of every segment
     __shared__ uint32_t scratch[NW + 1];
@@ -317,20 +327,20 @@ __global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
     const int sh = colbits - (int)b;
     const uint64_t beg = row_off[rows[h]] - base, end = row_off[rows[h] + 1] - base;
     const uint64_t qbase = hoff[h];
-    for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) segoff[d] = 0;
+    for (uint32_t d = threadIdx.x; d < nseg; d += kSplitRowThreads) segoff[d] = 0;
     __syncthreads();
-    for (uint64_t i = beg + threadIdx.x; i < end; i += kSplitThreads) atomicAdd(&segoff[stage[i].col >> sh], 1u);
+    for (uint64_t i = beg + threadIdx.x; i < end; i += kSplitRowThreads) atomicAdd(&segoff[stage[i].col >> sh], 1u);
     __syncthreads();
     {   // exclusive scan of the segment counts -> segment offsets
         const uint32_t c = threadIdx.x < nseg ? segoff[threadIdx.x] : 0u;
         uint32_t total;
-        const uint32_t ex = block_excl_scan<uint32_t, kSplitThreads>(c, scratch, &total);
+        const uint32_t ex = block_excl_scan<uint32_t, kSplitRowThreads>(c, scratch, &total);
         if (threadIdx.x < nseg) { segoff[threadIdx.x] = ex; vrow_off[vbase[h] + threadIdx.x] = qbase + ex; }
     }
     __syncthreads();
     for (uint64_t sb = beg; sb < end; sb += kSplitRowStretch) {
         const uint64_t se = min(sb + (uint64_t)kSplitRowStretch, end);
-        for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) {
+        for (uint32_t d = threadIdx.x; d < nseg; d += kSplitRowThreads) {
 #pragma unroll
             for (int ww = 0; ww < NW; ww++) cnt[ww][d] = 0;
         }
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
         }
         __syncthreads();
         // per segment: exclusive offsets of the waves inside this stretch; cnt[NW] keeps the stretch's total
-        for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) {
+        for (uint32_t d = threadIdx.x; d < nseg; d += kSplitRowThreads) {
             uint32_t run = 0;
 #pragma unroll
             for (int ww = 0; ww < NW; ww++) { const uint32_t c = cnt[ww][d]; cnt[ww][d] = (uint16_t)run; run += c; }
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(kSplitThreads) void split_row_kernel(
             }
         }
         __syncthreads();
-        for (uint32_t d = threadIdx.x; d < nseg; d += kSplitThreads) segoff[d] += cnt[NW][d];
+        for (uint32_t d = threadIdx.x; d < nseg; d += kSplitRowThreads) segoff[d] += cnt[NW][d];
         // (the zeroing of cnt at the top of the next round touches the same d from the same thread)
     }
 }
