@@ -328,8 +328,22 @@ __global__ __launch_bounds__(kSplitRowThreads) void split_row_kernel(
     const uint64_t beg = row_off[rows[h]] - base, end = row_off[rows[h] + 1] - base;
     const uint64_t qbase = hoff[h];
     for (uint32_t d = threadIdx.x; d < nseg; d += kSplitRowThreads) segoff[d] = 0;
-    __syncthreads();
-    for (uint64_t i = beg + threadIdx.x; i < end; i += kSplitRowThreads) atomicAdd(&segoff[stage[i].col >> sh], 1u);
+    // the records of the FIRST round are loaded whole and kept for its scatter (a third of the long-row records sit in the
+    // first 4096 entries of their row: read once instead of twice); the rest of the row is counted from its column words
+    PartWords<T> rec[ITERS];
+    {
+        const uint64_t se0 = min(beg + (uint64_t)kSplitRowStretch, end), wbeg0 = beg + (uint64_t)w * (kSplitRowStretch / NW);
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const uint64_t i = wbeg0 + (uint64_t)it * kWave + lane;
+            rec[it] = load_part_words(&stage[i < se0 ? i : beg]);  // branch-free: lanes past the end re-read the first record
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITERS; it++)
+            if (wbeg0 + (uint64_t)it * kWave + lane < se0) atomicAdd(&segoff[rec[it].col() >> sh], 1u);
+    }
+    for (uint64_t i = beg + kSplitRowStretch + threadIdx.x; i < end; i += kSplitRowThreads) atomicAdd(&segoff[stage[i].col >> sh], 1u);
     __syncthreads();
     {   // exclusive scan of the segment counts -> segment offsets
         const uint32_t c = threadIdx.x < nseg ? segoff[threadIdx.x] : 0u;
@@ -347,11 +361,12 @@ __global__ __launch_bounds__(kSplitRowThreads) void split_row_kernel(
         __syncthreads();  // also orders the segoff update of the previous round before this round's scatter
         const uint64_t wbeg = sb + (uint64_t)w * (kSplitRowStretch / NW);
         uint32_t rk[ITERS];
-        PartWords<T> rec[ITERS];
+        if (sb != beg) {
 #pragma unroll
-        for (int it = 0; it < ITERS; it++) {
-            const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
-            rec[it] = load_part_words(&stage[i < se ? i : sb]);  // branch-free: lanes past the end re-read the first record
+            for (int it = 0; it < ITERS; it++) {
+                const uint64_t i = wbeg + (uint64_t)it * kWave + lane;
+                rec[it] = load_part_words(&stage[i < se ? i : sb]);
+            }
         }
 #pragma unroll
         for (int it = 0; it < ITERS; it++) {
