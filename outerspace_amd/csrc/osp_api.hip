@@ -534,7 +534,12 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         vbase = sc.get<uint64_t>((uint64_t)nlong + 1);
         // debugging aid: OSP_SPLIT_ROW_MAX moves the boundary between the two split kernels (tests run both on small inputs)
         const uint64_t row_max = getenv("OSP_SPLIT_ROW_MAX") ? strtoull(getenv("OSP_SPLIT_ROW_MAX"), nullptr, 10) : kSplitRowMax;
-        split_params_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(p0.long_rows, nlong, io.row_off, colbits, row_max, hbits, nstretch, nseg, nhist);
+        // no more ranges than make a range as narrow as the dense accumulators take (osp_split.h, kDenseBits): beyond that
+        // a finer split only shortens the runs the scatter writes -- whatever a range of <= 1024 columns holds is summed
+        // without a sort.  (Only bites when N < 2^22: 4096 ranges of 1024 columns.)
+        const int bits_cap = getenv("OSP_SPLIT_BITS_CAP") ? atoi(getenv("OSP_SPLIT_BITS_CAP")) : std::max(colbits - kDenseBits, kSplitRowBits);
+        split_params_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(p0.long_rows, nlong, io.row_off, colbits, row_max, bits_cap, hbits, nstretch, nseg,
+                                                                 nhist);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nstretch}, nlong, blkbase, hscan_tmp, s);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nseg}, nlong, vbase, hscan_tmp, s);
         device_exclusive_scan<LoadU64, uint64_t>(LoadU64{nhist}, nlong, hbase, hscan_tmp, s);

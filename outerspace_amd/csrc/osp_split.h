@@ -32,20 +32,23 @@ constexpr int kSplitJob = OSP_SPLIT_JOB_ROUNDS * kSplitStretch;  // entries of o
                                               // eight rounds share ONE histogram column (a 4096-cell column per 4096
                                               // entries was a third of the split's traffic on Graph500 inputs)
 constexpr int kSplitMaxBits = 12;     // at most 4096 segments per row
-constexpr int kSplitTarget = 256;     // aim for segments of about this many entries
+#ifndef OSP_SPLIT_TARGET
+#define OSP_SPLIT_TARGET 256
+#endif
+constexpr int kSplitTarget = OSP_SPLIT_TARGET;     // aim for segments of about this many entries
 constexpr int kSplitRowBits = 8;      // rows of at most 2^8 segments (<= 64K entries) are split by ONE workgroup
 constexpr uint64_t kSplitRowMax = (uint64_t)kSplitTarget << kSplitRowBits;  // longer rows: one workgroup per stretch
 
 // per long row h: b = number of split bits, and the sizes that get scanned
 __global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *row_off, int colbits,
-                                    uint64_t row_max, uint8_t *hbits, uint32_t *nstretch, uint32_t *nseg, uint64_t *nhist) {
+                                    uint64_t row_max, int bits_cap, uint8_t *hbits, uint32_t *nstretch, uint32_t *nseg, uint64_t *nhist) {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= nheavy) return;
     const uint64_t U = row_off[rows[h] + 1] - row_off[rows[h]];
     const uint64_t want = (U + kSplitTarget - 1) / kSplitTarget;
     int b = 1;
     while (b < kSplitMaxBits && (1ull << b) < want) b++;
-    b = min(b, colbits);
+    b = min(b, min(colbits, bits_cap));
     const bool big = U > row_max || b > kSplitRowBits;
     const uint32_t ns = big ? (uint32_t)((U + kSplitJob - 1) / kSplitJob) : 0u;  // 0 stretches = one-workgroup row
     hbits[h] = (uint8_t)b;
@@ -221,7 +224,10 @@ __global__ void split_vrows_kernel(uint32_t nheavy, const uint64_t *vbase, const
 // sort-and-sum would use -- same bits -- and different columns proceed in parallel.  A bitmap remembers which columns
 // occurred (a sum that cancels to zero is still an entry).  The compacted (column, sum) pairs go back over the segment's
 // own beginning, like the other paths for over-long segments.
-constexpr int kDenseBits = 10;  // segments whose column range is at most 2^10 columns
+#ifndef OSP_DENSE_BITS
+#define OSP_DENSE_BITS 10
+#endif
+constexpr int kDenseBits = OSP_DENSE_BITS;  // segments whose column range is at most 2^10 columns
 struct SegDenseFlag {
     const uint32_t *list;   // over-long segments (virtual rows)
     const uint64_t *vbase;  // first segment of every long row
