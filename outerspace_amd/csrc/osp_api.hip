@@ -46,6 +46,9 @@ struct Context {
     // stable radix ranks from the return order of LDS atomics (true) or from ballot matching (false): decided when the
     // context is created (self-test; OSP_RANK=ballot|atomic overrides), see osp_prims.h
     bool rank_atomic = OSP_RANK_ATOMIC != 0;
+    // dense accumulation of narrow over-long segments (osp_split.h) by LDS floating-point atomics (f64) or by ballot ranks
+    // and rounds: same decision procedure (self-test; OSP_DENSE_ADD=ballot|atomic overrides)
+    bool dense_atomic = true;
     // pool misses (OSP_VERBOSE prints them per product): device allocations are slow, a product should not need any
     // once the pool is warm
     uint64_t malloc_calls = 0, malloc_bytes = 0;
@@ -606,7 +609,11 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
                 if (ndense) {
                     uint32_t *dense_list = sc.get<uint32_t>(ndense), *others = sc.get<uint32_t>(nseg_long - ndense);
                     seg_split_list_kernel<SegDenseFlag><<<grid_for(nseg_long, 256), 256, 0, s>>>(df, hscan, nseg_long, dense_list, others);
-                    dense_segment_kernel<T><<<grid_for(ndense, 4), 256, 0, s>>>(dense_list, ndense, vrow_off, vbase, hbits, nlong, colbits, qstage,
+                    if (ctx->dense_atomic)
+                        dense_segment_kernel<T, true><<<grid_for(ndense, 4), 256, 0, s>>>(dense_list, ndense, vrow_off, vbase, hbits, nlong, colbits, qstage,
+                                                                              seg_nnz);
+                    else
+                        dense_segment_kernel<T, false><<<grid_for(ndense, 4), 256, 0, s>>>(dense_list, ndense, vrow_off, vbase, hbits, nlong, colbits, qstage,
                                                                               seg_nnz);
                     res->info.dense_segments += ndense;
                     rest_list = others;
@@ -1446,6 +1453,19 @@ static int context_create(int device, void *stream, bool own, osp_context_t *out
             if (d2h(bad, c->stream) != 0) {
                 c->rank_atomic = false;
                 if (getenv("OSP_VERBOSE")) fprintf(stderr, "[osp] LDS atomics do not return old values in lane order on this device: using ballot ranks\n");
+            }
+        }
+        const char *fadd = getenv("OSP_DENSE_ADD");
+        if (fadd && strcmp(fadd, "ballot") == 0) c->dense_atomic = false;
+        else if (fadd && strcmp(fadd, "atomic") == 0) c->dense_atomic = true;
+        if (c->dense_atomic) {
+            Scratch sc(c);
+            uint32_t *bad = sc.get<uint32_t>(1);
+            OSP_HIP(hipMemsetAsync(bad, 0, sizeof(uint32_t), c->stream));
+            fadd_order_selftest_kernel<<<64, 256, 0, c->stream>>>(bad);
+            if (d2h(bad, c->stream) != 0) {
+                c->dense_atomic = false;
+                if (getenv("OSP_VERBOSE")) fprintf(stderr, "[osp] LDS floating-point atomics do not add in lane order on this device: dense segments by ballot ranks\n");
             }
         }
     } catch (...) {

@@ -241,6 +241,35 @@ struct SegDenseFlag {
         return (colbits - (int)hbits[h]) <= kDenseBits ? 1u : 0u;
     }
 };
+// Does one ds_add_f64 apply the lanes that hit the same address in ascending lane order?  Every wave adds 64 values of
+// wildly different magnitude (so that any other order changes the bits) to a few accumulators, once by the atomic and once
+// lane by lane, and compares the bits.
+__global__ __launch_bounds__(256) void fadd_order_selftest_kernel(uint32_t *bad) {
+    __shared__ double acc[4][8], ref[4][8];
+    const unsigned tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    uint32_t x = 0x9E3779B9u * (blockIdx.x * 256u + tid + 1u), nbad = 0;
+    for (int r = 0; r < 64; r++) {
+        if (lane < 8) { acc[w][lane] = -0.0; ref[w][lane] = -0.0; }
+        __builtin_amdgcn_wave_barrier();
+        for (int it = 0; it < 4; it++) {
+            x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+            const unsigned c = (x >> 9) & ((r & 1) ? 1u : 7u);
+            const bool valid = ((x >> 27) & 7u) != 0;
+            // mantissa from x, exponent spread over 2^-40 .. 2^40, both signs
+            const double v = __longlong_as_double((long long)(((uint64_t)(x & 0x80000000u) << 32) |
+                                                              ((uint64_t)(1023 - 40 + ((x >> 3) % 81u)) << 52) | ((uint64_t)x * 0x9E3779B97F4A7ull & 0xFFFFFFFFFFFFFull)));
+            if (valid) __hip_atomic_fetch_add(&acc[w][c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (unsigned l = 0; l < kWave; l++) {   // the reference: lane by lane
+                if (lane == l && valid) ref[w][c] += v;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 8) nbad += __double_as_longlong(acc[w][lane]) != __double_as_longlong(ref[w][lane]);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
 // list[t] -> yes[scan[t]] or no[t - scan[t]]; scan = exclusive scan of the flags
 template <class F>
 __global__ void seg_split_list_kernel(F f, const uint32_t *scan, uint32_t n, uint32_t *yes, uint32_t *no) {
@@ -248,7 +277,14 @@ __global__ void seg_split_list_kernel(F f, const uint32_t *scan, uint32_t n, uin
     if (t >= n) return;
     if (f(t)) yes[scan[t]] = f.list[t]; else no[t - scan[t]] = f.list[t];
 }
-template <class T>
+// FA (f64 only): the additions are ONE LDS floating-point atomic per group of 64 entries instead of ballot ranks and
+// rounds.  Lanes of one ds_add_f64 that hit the same accumulator are applied in ascending lane order -- the same property
+// of the LDS atomic unit the stable ranks rest on (osp_kernels.h), equally undocumented, so fadd_order_selftest_kernel
+// checks it on the device when the context is created and the ballot form below stays as the fallback -- and successive
+// instructions of a wave execute in order: every column's sum is formed in staging order.  An accumulator starts as
+// -0.0, the one value with (-0.0) + x == x for every x: "the sum starts AS the first entry" without telling first from
+// later entries.
+template <class T, bool FA = false>
 __global__ __launch_bounds__(256) void dense_segment_kernel(const uint32_t *list, uint32_t nlist, const uint64_t *vrow_off, const uint64_t *vbase,
                                                           const uint8_t *hbits, uint32_t nlong, int colbits, Part<T> *qstage,
                                                           uint32_t *seg_nnz) {
@@ -264,9 +300,33 @@ __global__ __launch_bounds__(256) void dense_segment_kernel(const uint32_t *list
     const uint32_t cbase = (uint32_t)((v - vbase[h]) << sh), R = 1u << sh;
     const uint64_t s0 = vrow_off[v], m = vrow_off[v + 1] - s0;
     for (uint32_t c = lane; c < R / 32 + (R < 32 ? 1u : 0u); c += kWave) seen[w][c] = 0u;
+    constexpr bool ATOMIC = FA && sizeof(T) == 8;
+    if constexpr (ATOMIC) {
+        for (uint32_t c = lane; c < R; c += kWave) acc[w][c] = T(-0.0);
+    }
     __builtin_amdgcn_wave_barrier();
     Part<T> *seg = qstage + s0;
-    for (uint64_t i0 = 0; i0 < m; i0 += kWave) {
+    if constexpr (ATOMIC) {
+        constexpr int UNROLL = 4;  // four groups of loads in flight; the atomics are issued group by group, in order
+        for (uint64_t i0 = 0; i0 < m; i0 += (uint64_t)UNROLL * kWave) {
+            PartWords<T> rec[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                const uint64_t i = i0 + (uint64_t)u * kWave + lane;
+                rec[u] = load_part_words(&seg[i < m ? i : 0]);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                const uint64_t i = i0 + (uint64_t)u * kWave + lane;
+                if (i < m) {
+                    const uint32_t rel = rec[u].col() - cbase;
+                    __hip_atomic_fetch_add(&acc[w][rel], rec[u].val(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    atomicOr(&seen[w][rel >> 5], 1u << (rel & 31u));
+                }
+            }
+        }
+    }
+    for (uint64_t i0 = 0; !ATOMIC && i0 < m; i0 += kWave) {
         const uint64_t i = i0 + lane;
         const bool valid = i < m;
         const PartWords<T> rec = load_part_words(&seg[valid ? i : 0]);
