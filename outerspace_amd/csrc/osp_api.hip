@@ -610,10 +610,10 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
                     uint32_t *dense_list = sc.get<uint32_t>(ndense), *others = sc.get<uint32_t>(nseg_long - ndense);
                     seg_split_list_kernel<SegDenseFlag><<<grid_for(nseg_long, 256), 256, 0, s>>>(df, hscan, nseg_long, dense_list, others);
                     if (ctx->dense_atomic)
-                        dense_segment_kernel<T, true><<<grid_for(ndense, 4), 256, 0, s>>>(dense_list, ndense, vrow_off, vbase, hbits, nlong, colbits, qstage,
+                        dense_segment_kernel<T, true><<<grid_for(ndense, kDenseWaves), kDenseWaves * kWave, 0, s>>>(dense_list, ndense, vrow_off, vbase, hbits, nlong, colbits, qstage,
                                                                               seg_nnz);
                     else
-                        dense_segment_kernel<T, false><<<grid_for(ndense, 4), 256, 0, s>>>(dense_list, ndense, vrow_off, vbase, hbits, nlong, colbits, qstage,
+                        dense_segment_kernel<T, false><<<grid_for(ndense, kDenseWaves), kDenseWaves * kWave, 0, s>>>(dense_list, ndense, vrow_off, vbase, hbits, nlong, colbits, qstage,
                                                                               seg_nnz);
                     res->info.dense_segments += ndense;
                     rest_list = others;

@@ -225,9 +225,11 @@ __global__ void split_vrows_kernel(uint32_t nheavy, const uint64_t *vbase, const
 // occurred (a sum that cancels to zero is still an entry).  The compacted (column, sum) pairs go back over the segment's
 // own beginning, like the other paths for over-long segments.
 #ifndef OSP_DENSE_BITS
-#define OSP_DENSE_BITS 10
+#define OSP_DENSE_BITS 11
 #endif
-constexpr int kDenseBits = OSP_DENSE_BITS;  // segments whose column range is at most 2^10 columns
+constexpr int kDenseBits = OSP_DENSE_BITS;  // segments whose column range is at most 2^kDenseBits columns
+// waves (= segments in progress) per workgroup: what fits 160 KB of LDS with f64 accumulators, at most four
+constexpr int kDenseWaves = kDenseBits <= 12 ? 4 : (kDenseBits == 13 ? 2 : 1);
 struct SegDenseFlag {
     const uint32_t *list;   // over-long segments (virtual rows)
     const uint64_t *vbase;  // first segment of every long row
@@ -285,10 +287,10 @@ __global__ void seg_split_list_kernel(F f, const uint32_t *scan, uint32_t n, uin
 // -0.0, the one value with (-0.0) + x == x for every x: "the sum starts AS the first entry" without telling first from
 // later entries.
 template <class T, bool FA = false>
-__global__ __launch_bounds__(256) void dense_segment_kernel(const uint32_t *list, uint32_t nlist, const uint64_t *vrow_off, const uint64_t *vbase,
-                                                          const uint8_t *hbits, uint32_t nlong, int colbits, Part<T> *qstage,
-                                                          uint32_t *seg_nnz) {
-    constexpr int NW = 256 / kWave, R_MAX = 1 << kDenseBits;
+__global__ __launch_bounds__(kDenseWaves * kWave) void dense_segment_kernel(const uint32_t *list, uint32_t nlist, const uint64_t *vrow_off,
+                                                                          const uint64_t *vbase, const uint8_t *hbits, uint32_t nlong, int colbits,
+                                                                          Part<T> *qstage, uint32_t *seg_nnz) {
+    constexpr int NW = kDenseWaves, R_MAX = 1 << kDenseBits;
     __shared__ T acc[NW][R_MAX];
     __shared__ uint32_t seen[NW][R_MAX / 32];
     const unsigned lane = lane_id(), w = threadIdx.x >> 6;
