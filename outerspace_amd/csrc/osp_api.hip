@@ -48,7 +48,7 @@ struct Context {
     bool rank_atomic = OSP_RANK_ATOMIC != 0;
     // dense accumulation of narrow over-long segments (osp_split.h) by LDS floating-point atomics (f64) or by ballot ranks
     // and rounds: same decision procedure (self-test; OSP_DENSE_ADD=ballot|atomic overrides)
-    bool dense_atomic = true;
+    bool dense_atomic[2] = {true, true};  // [0] f32, [1] f64
     // pool misses (OSP_VERBOSE prints them per product): device allocations are slow, a product should not need any
     // once the pool is warm
     uint64_t malloc_calls = 0, malloc_bytes = 0;
@@ -609,7 +609,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
                 if (ndense) {
                     uint32_t *dense_list = sc.get<uint32_t>(ndense), *others = sc.get<uint32_t>(nseg_long - ndense);
                     seg_split_list_kernel<SegDenseFlag><<<grid_for(nseg_long, 256), 256, 0, s>>>(df, hscan, nseg_long, dense_list, others);
-                    if (ctx->dense_atomic)
+                    if (ctx->dense_atomic[sizeof(T) == 8])
                         dense_segment_kernel<T, true><<<grid_for(ndense, kDenseWaves), kDenseWaves * kWave, 0, s>>>(dense_list, ndense, vrow_off, vbase, hbits, nlong, colbits, qstage,
                                                                               seg_nnz);
                     else
@@ -1456,16 +1456,20 @@ static int context_create(int device, void *stream, bool own, osp_context_t *out
             }
         }
         const char *fadd = getenv("OSP_DENSE_ADD");
-        if (fadd && strcmp(fadd, "ballot") == 0) c->dense_atomic = false;
-        else if (fadd && strcmp(fadd, "atomic") == 0) c->dense_atomic = true;
-        if (c->dense_atomic) {
+        for (int wide = 0; wide < 2; wide++) {
+            if (fadd && strcmp(fadd, "ballot") == 0) c->dense_atomic[wide] = false;
+            else if (fadd && strcmp(fadd, "atomic") == 0) c->dense_atomic[wide] = true;
+            if (!c->dense_atomic[wide]) continue;
             Scratch sc(c);
             uint32_t *bad = sc.get<uint32_t>(1);
             OSP_HIP(hipMemsetAsync(bad, 0, sizeof(uint32_t), c->stream));
-            fadd_order_selftest_kernel<<<64, 256, 0, c->stream>>>(bad);
+            if (wide) fadd_order_selftest_kernel<double><<<64, 256, 0, c->stream>>>(bad);
+            else fadd_order_selftest_kernel<float><<<64, 256, 0, c->stream>>>(bad);
             if (d2h(bad, c->stream) != 0) {
-                c->dense_atomic = false;
-                if (getenv("OSP_VERBOSE")) fprintf(stderr, "[osp] LDS floating-point atomics do not add in lane order on this device: dense segments by ballot ranks\n");
+                c->dense_atomic[wide] = false;
+                if (getenv("OSP_VERBOSE"))
+                    fprintf(stderr, "[osp] LDS %s atomics do not add in lane order (or flush subnormals) on this device: dense segments by ballot ranks\n",
+                            wide ? "f64" : "f32");
             }
         }
     } catch (...) {

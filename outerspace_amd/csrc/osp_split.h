@@ -246,20 +246,29 @@ struct SegDenseFlag {
 // Does one ds_add_f64 apply the lanes that hit the same address in ascending lane order?  Every wave adds 64 values of
 // wildly different magnitude (so that any other order changes the bits) to a few accumulators, once by the atomic and once
 // lane by lane, and compares the bits.
+template <class T>
 __global__ __launch_bounds__(256) void fadd_order_selftest_kernel(uint32_t *bad) {
-    __shared__ double acc[4][8], ref[4][8];
+    __shared__ T acc[4][8], ref[4][8];
     const unsigned tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     uint32_t x = 0x9E3779B9u * (blockIdx.x * 256u + tid + 1u), nbad = 0;
     for (int r = 0; r < 64; r++) {
-        if (lane < 8) { acc[w][lane] = -0.0; ref[w][lane] = -0.0; }
+        if (lane < 8) { acc[w][lane] = T(-0.0); ref[w][lane] = T(-0.0); }
         __builtin_amdgcn_wave_barrier();
         for (int it = 0; it < 4; it++) {
             x ^= x << 13; x ^= x >> 17; x ^= x << 5;
             const unsigned c = (x >> 9) & ((r & 1) ? 1u : 7u);
             const bool valid = ((x >> 27) & 7u) != 0;
-            // mantissa from x, exponent spread over 2^-40 .. 2^40, both signs
-            const double v = __longlong_as_double((long long)(((uint64_t)(x & 0x80000000u) << 32) |
-                                                              ((uint64_t)(1023 - 40 + ((x >> 3) % 81u)) << 52) | ((uint64_t)x * 0x9E3779B97F4A7ull & 0xFFFFFFFFFFFFFull)));
+            // mantissa from x, exponent spread over 2^-40 .. 2^40 (2^-12 .. 2^12 in f32), both signs; every eighth round:
+            // subnormals and their neighbours (exponent fields 0..2), which the atomic must not flush
+            T v;
+            if constexpr (sizeof(T) == 8) {
+                const uint64_t expo = (r & 7) == 7 ? (uint64_t)((x >> 3) % 3u) : (uint64_t)(1023 - 40 + ((x >> 3) % 81u));
+                v = __longlong_as_double((long long)(((uint64_t)(x & 0x80000000u) << 32) | (expo << 52) |
+                                                     ((uint64_t)x * 0x9E3779B97F4A7ull & 0xFFFFFFFFFFFFFull)));
+            } else {
+                const uint32_t expo = (r & 7) == 7 ? (x >> 3) % 3u : 127u - 12u + ((x >> 3) % 25u);
+                v = __uint_as_float((x & 0x80000000u) | (expo << 23) | ((x * 0x9E3779B9u) & 0x7FFFFFu));
+            }
             if (valid) __hip_atomic_fetch_add(&acc[w][c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             for (unsigned l = 0; l < kWave; l++) {   // the reference: lane by lane
                 if (lane == l && valid) ref[w][c] += v;
@@ -267,7 +276,10 @@ __global__ __launch_bounds__(256) void fadd_order_selftest_kernel(uint32_t *bad)
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (lane < 8) nbad += __double_as_longlong(acc[w][lane]) != __double_as_longlong(ref[w][lane]);
+        if (lane < 8) {
+            if constexpr (sizeof(T) == 8) nbad += __double_as_longlong(acc[w][lane]) != __double_as_longlong(ref[w][lane]);
+            else nbad += __float_as_uint(acc[w][lane]) != __float_as_uint(ref[w][lane]);
+        }
         __builtin_amdgcn_wave_barrier();
     }
     if (nbad) atomicAdd(bad, nbad);
@@ -279,10 +291,10 @@ __global__ void seg_split_list_kernel(F f, const uint32_t *scan, uint32_t n, uin
     if (t >= n) return;
     if (f(t)) yes[scan[t]] = f.list[t]; else no[t - scan[t]] = f.list[t];
 }
-// FA (f64 only): the additions are ONE LDS floating-point atomic per group of 64 entries instead of ballot ranks and
-// rounds.  Lanes of one ds_add_f64 that hit the same accumulator are applied in ascending lane order -- the same property
+// FA: the additions are ONE LDS floating-point atomic per group of 64 entries instead of ballot ranks and
+// rounds.  Lanes of one ds_add_f64 / ds_add_f32 that hit the same accumulator are applied in ascending lane order -- the same property
 // of the LDS atomic unit the stable ranks rest on (osp_kernels.h), equally undocumented, so fadd_order_selftest_kernel
-// checks it on the device when the context is created and the ballot form below stays as the fallback -- and successive
+// checks it (and that subnormals are not flushed) for each value type on the device when the context is created and the ballot form below stays as the fallback -- and successive
 // instructions of a wave execute in order: every column's sum is formed in staging order.  An accumulator starts as
 // -0.0, the one value with (-0.0) + x == x for every x: "the sum starts AS the first entry" without telling first from
 // later entries.
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(kDenseWaves * kWave) void dense_segment_kernel(cons
     const uint32_t cbase = (uint32_t)((v - vbase[h]) << sh), R = 1u << sh;
     const uint64_t s0 = vrow_off[v], m = vrow_off[v + 1] - s0;
     for (uint32_t c = lane; c < R / 32 + (R < 32 ? 1u : 0u); c += kWave) seen[w][c] = 0u;
-    constexpr bool ATOMIC = FA && sizeof(T) == 8;
+    constexpr bool ATOMIC = FA;
     if constexpr (ATOMIC) {
         for (uint32_t c = lane; c < R; c += kWave) acc[w][c] = T(-0.0);
     }

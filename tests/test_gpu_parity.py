@@ -739,9 +739,9 @@ def test_rmat22_full_size_properties_and_slab_parity(ctx, port):
 
 @pytest.mark.parametrize("how", ["atomic", "ballot"])
 def test_dense_accumulation_both_ways(port, monkeypatch, how):
-    """The dense accumulators add either with one LDS floating-point atomic per 64 entries (f64; lanes that hit one
-    accumulator are applied in lane order -- self-tested when the context is created) or by ballot ranks and rounds (the
-    fallback, and f32).  OSP_DENSE_ADD forces either: same bits as the oracle on products whose hub rows go through them,
+    """The dense accumulators add either with one LDS floating-point atomic per 64 entries (lanes that hit one
+    accumulator are applied in lane order -- self-tested for f32 and f64 when the context is created) or by ballot ranks
+    and rounds (the fallback).  OSP_DENSE_ADD forces either: same bits as the oracle on products whose hub rows go through them,
     with exact cancellation and a lone negative zero among the piles."""
     from outerspace_amd import spgemm as S
     monkeypatch.setenv("OSP_DENSE_ADD", how)
