@@ -802,7 +802,7 @@ constexpr int merge_wgs_per_cu() {
 }
 template <class T, int NT, int CAP, int MAXWG = kMergeMaxWgs, int ABL = 0>
 constexpr int merge_waves_per_simd() {
-    const int w = merge_wgs_per_cu<T, NT, CAP, MAXWG, ABL>() * NT / 256;
+    const int w = (merge_wgs_per_cu<T, NT, CAP, MAXWG, ABL>() * NT + 255) / 256;  // (rounded up: 3 workgroups of 6 waves need 5 per SIMD)
     return w > 8 ? 8 : (w < 1 ? 1 : w);
 }
 // RA: stable ranks from the return order of one LDS atomic (true) or from ballot matching (false); a context whose
@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
             OSP_PROF_MARK(3);
             // (b) exclusive scan over (digit major, wave minor); a thread owns dpt consecutive digits
             if constexpr ((ABL & 128) != 0 || DPT != 4) {
-                const int dpt = ndig > NT ? ndig / NT : 1;  // ndig and NT are powers of two
+                const int dpt = (ndig + NT - 1) / NT;  // (bounds-checked below: NT need not be a power of two)
                 uint32_t c[DPT][NW], ssum = 0;
 #pragma unroll
                 for (int q = 0; q < DPT; q++) {

@@ -19,6 +19,9 @@ constexpr int kSplitThreads = 256;
 #ifndef OSP_SPLIT_ROW_THREADS
 #define OSP_SPLIT_ROW_THREADS 1024
 #endif
+#ifndef OSP_SPLIT_ROW_PRE
+#define OSP_SPLIT_ROW_PRE 1
+#endif
 constexpr int kSplitRowThreads = OSP_SPLIT_ROW_THREADS;  // split_row_kernel's workgroup: 16 waves on one row (see the notes at the kernel)
 #ifndef OSP_SPLIT_ROW_STRETCH
 #define OSP_SPLIT_ROW_STRETCH 4096
@@ -387,7 +390,9 @@ __global__ __launch_bounds__(kDenseWaves * kWave) void dense_segment_kernel(cons
 //     it waits for is the second read of rows that more rows in flight have pushed out of L2 (FETCH_SIZE: every row read
 //     twice).  Hence the opposite: FEWER rows in flight, each finished sooner -- workgroups of 1024 threads (4 records per
 //     thread and round): 17.0 ms; 512 threads 17.7; one such workgroup per CU instead of two 16.8 (not kept: within noise);
-//     rounds of 8192 / 16384 entries with 1024 threads 21.5.
+//     rounds of 8192 / 16384 entries with 1024 threads 21.5.  The first round's records kept in registers from the
+//     histogram to the scatter: 16.4 ms (FETCH_SIZE 27.8 -> 22.0 GB per launch); the first TWO rounds'
+//     (-DOSP_SPLIT_ROW_PRE=2, 62 registers): 16.5 ms -- no further gain, the read volume is no longer what it waits for.
 template <class T, bool RA>
 __global__ __launch_bounds__(kSplitRowThreads) void split_row_kernel(
     const uint32_t *rows, uint32_t nheavy, const uint8_t *hbits, const uint32_t *nstretch, const uint64_t *vbase,
@@ -411,19 +416,35 @@ __global__ __launch_bounds__(kSplitRowThreads) void split_row_kernel(
     // the records of the FIRST round are loaded whole and kept for its scatter (a third of the long-row records sit in the
     // first 4096 entries of their row: read once instead of twice); the rest of the row is counted from its column words
     PartWords<T> rec[ITERS];
+#if OSP_SPLIT_ROW_PRE >= 2
+    PartWords<T> rec1[ITERS];  // ... and the second round's (rows of up to 8192 entries are then read once)
+#endif
     {
-        const uint64_t se0 = min(beg + (uint64_t)kSplitRowStretch, end), wbeg0 = beg + (uint64_t)w * (kSplitRowStretch / NW);
+        const uint64_t wbeg0 = beg + (uint64_t)w * (kSplitRowStretch / NW);
 #pragma unroll
         for (int it = 0; it < ITERS; it++) {
             const uint64_t i = wbeg0 + (uint64_t)it * kWave + lane;
-            rec[it] = load_part_words(&stage[i < se0 ? i : beg]);  // branch-free: lanes past the end re-read the first record
+            rec[it] = load_part_words(&stage[i < end ? i : beg]);  // branch-free: lanes past the end re-read the first record
         }
+#if OSP_SPLIT_ROW_PRE >= 2
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const uint64_t i = wbeg0 + kSplitRowStretch + (uint64_t)it * kWave + lane;
+            rec1[it] = load_part_words(&stage[i < end ? i : beg]);
+        }
+#endif
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < ITERS; it++)
-            if (wbeg0 + (uint64_t)it * kWave + lane < se0) atomicAdd(&segoff[rec[it].col() >> sh], 1u);
+            if (wbeg0 + (uint64_t)it * kWave + lane < end) atomicAdd(&segoff[rec[it].col() >> sh], 1u);
+#if OSP_SPLIT_ROW_PRE >= 2
+#pragma unroll
+        for (int it = 0; it < ITERS; it++)
+            if (wbeg0 + kSplitRowStretch + (uint64_t)it * kWave + lane < end) atomicAdd(&segoff[rec1[it].col() >> sh], 1u);
+#endif
     }
-    for (uint64_t i = beg + kSplitRowStretch + threadIdx.x; i < end; i += kSplitRowThreads) atomicAdd(&segoff[stage[i].col >> sh], 1u);
+    for (uint64_t i = beg + (uint64_t)OSP_SPLIT_ROW_PRE * kSplitRowStretch + threadIdx.x; i < end; i += kSplitRowThreads)
+        atomicAdd(&segoff[stage[i].col >> sh], 1u);
     __syncthreads();
     {   // exclusive scan of the segment counts -> segment offsets
         const uint32_t c = threadIdx.x < nseg ? segoff[threadIdx.x] : 0u;
@@ -441,6 +462,12 @@ __global__ __launch_bounds__(kSplitRowThreads) void split_row_kernel(
         __syncthreads();  // also orders the segoff update of the previous round before this round's scatter
         const uint64_t wbeg = sb + (uint64_t)w * (kSplitRowStretch / NW);
         uint32_t rk[ITERS];
+#if OSP_SPLIT_ROW_PRE >= 2
+        if (sb == beg + kSplitRowStretch) {
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) rec[it] = rec1[it];
+        } else
+#endif
         if (sb != beg) {
 #pragma unroll
             for (int it = 0; it < ITERS; it++) {

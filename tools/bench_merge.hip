@@ -61,7 +61,7 @@ float run_runs(uint32_t *tile_rows, uint32_t ntiles, uint64_t M, uint64_t *row_o
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     CK(hipMemsetAsync(status, 0, (uint64_t)ntiles * 8, 0));
-    CK(hipMemsetAsync(ticket, 0, kTicketBytes, 0));
+    CK(hipMemsetAsync(ticket, 0, sizeof(uint32_t), 0));
     CK(hipMemsetAsync(outn, 0, 16, 0));
     CK(hipEventRecord(a, 0));
     merge_runs_kernel<double, NT, ABL><<<ntiles, NT, 0, 0>>>(tile_rows, ntiles, M, row_off, 0, g_arow, g_chunk_start, g_stage, heavy,
@@ -89,7 +89,7 @@ float run(uint32_t *tile_rows, uint32_t ntiles, uint64_t M, uint64_t *row_off, u
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     CK(hipMemsetAsync(status, 0, (uint64_t)ntiles * 8, 0));
-    CK(hipMemsetAsync(ticket, 0, kTicketBytes, 0));
+    CK(hipMemsetAsync(ticket, 0, sizeof(uint32_t), 0));
     CK(hipMemsetAsync(outn, 0, 16, 0));
     CK(hipEventRecord(a, 0));
     MergeLevels<double> lv{};
@@ -124,7 +124,7 @@ int main(int argc, char **argv) {
     uint32_t *pcol, *tile_rows, *heavy, *ticket, *ccol; double *pval, *cval; uint64_t *row_off, *status, *outn; int64_t *rowptr;
     CK(hipMalloc(&pcol, P * 4)); CK(hipMalloc(&pval, P * 8)); CK(hipMalloc(&ccol, (P + 4096ull * 0) * 4 + (uint64_t)ntiles * 3072 * 4));
     CK(hipMalloc(&cval, (uint64_t)ntiles * 3072 * 8 + P * 8)); CK(hipMalloc(&row_off, (M + 1) * 8)); CK(hipMalloc(&tile_rows, ntiles * 4));
-    CK(hipMalloc(&heavy, M * 4)); CK(hipMalloc(&status, (uint64_t)ntiles * 8)); CK(hipMalloc(&ticket, kTicketBytes)); CK(hipMalloc(&outn, 16));
+    CK(hipMalloc(&heavy, M * 4)); CK(hipMalloc(&status, (uint64_t)ntiles * 8)); CK(hipMalloc(&ticket, sizeof(uint32_t))); CK(hipMalloc(&outn, 16));
     CK(hipMalloc(&rowptr, (M + 1) * 8));
     const uint32_t clen = argc > 4 ? atoi(argv[4]) : 16;
     fill_kernel<<<(unsigned)((P + 255) / 256), 256>>>(pcol, pval, P);
@@ -158,6 +158,7 @@ int main(int argc, char **argv) {
         {"radix NT256 cap1536 4wg", 1536, run<256, 0, 1536, 4>}, {"radix NT256 cap1792 full", 1792, run<256, 0, 1792>},
         {"radix NT256 cap2048 full", 2048, run<256, 0, 2048>}, {"radix NT256 cap1280 6wg", 1280, run<256, 0, 1280, 6>},
         {"radix NT512 cap3072 full", 3072, run<512, 0, 3072>},
+        {"radix NT384 cap2304 full", 2304, run<384, 0, 2304>}, {"radix NT320 cap1920 full", 1920, run<320, 0, 1920>},
         {"runs NT1024 full", 3072, run_runs<1024, 0>},
     };
     if (getenv("CHECK_GRIDS")) {
