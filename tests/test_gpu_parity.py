@@ -849,6 +849,51 @@ def test_panel_boundaries_sweep(ctx, preset, scale, dt):
     ref.close()
 
 
+@pytest.mark.parametrize("preset,scale", [("mild", 18), ("g500", 15)])
+def test_slab_and_shard_sweep(ctx, preset, scale):
+    """The units the multi-GPU modes compute -- a k slab of the operands, a row shard of the result, both at once -- each at
+    a random staging capacity against the same unit in one panel: forty random units, same bits."""
+    import torch
+    from outerspace_amd.distributed import _as_tensor
+    dev = torch.device("cuda", 0)
+    n, csr, csc = _bench_module().rmat_device(scale, 16, gen.RMAT_PRESETS[preset], 11, dev, torch.float64)
+    torch.cuda.synchronize()
+    ptrs = [t.data_ptr() for t in (*csc, *csr)]
+    rng = np.random.default_rng(7)
+
+    def unit(**kw):
+        r = ctx.spgemm_csc_csr_device(np.float64, n, n, n, ptrs, **kw)
+        rp, ci, va = r.device_ptrs()
+        nr = r.info["row_end"] - r.info["row_begin"] if kw.get("row_shard") else n
+        out = (_as_tensor(rp, nr + 1, "<i8", dev, torch.int64).clone(), _as_tensor(ci, r.nnz, "<i4", dev, torch.int32).clone(),
+               _as_tensor(va, r.nnz, "<f8", dev, torch.float64).view(torch.int64).clone(), r.info["partials"], r.info["panels"])
+        r.close()
+        return out
+    done = 0
+    for it in range(40):
+        kw = {}
+        if it % 3 != 0:
+            k0 = int(rng.integers(0, n - 1))
+            kw["k_range"] = (k0, int(rng.integers(k0 + 1, min(n, k0 + 1 + n // int(rng.integers(1, 9))) + 1)))
+        if it % 2 == 1:
+            G = int(rng.integers(2, 6))
+            kw["row_shard"] = (int(rng.integers(0, G)), G)
+        ref = unit(**kw)
+        if ref[3] < 4096:
+            continue
+        cap = int(rng.integers(ref[3] // 9 + 1, ref[3] // 2 + 2))
+        try:
+            got = unit(partial_capacity=cap, **kw)
+        except RuntimeError as e:   # one row alone can exceed a small capacity: an error by contract
+            assert "staging capacity" in str(e)
+            continue
+        assert got[3] == ref[3] and got[4] > 1, (kw, cap)
+        for a, b in zip(got[:3], ref[:3]):
+            assert torch.equal(a, b), (kw, cap)
+        done += 1
+    assert done >= 20
+
+
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 def test_long_runs_inside_tiles(ctx, port, dt):
     """Runs longer than kRunShort inside ordinary tiles (an output entry fed by dozens to hundreds of products) are summed by
