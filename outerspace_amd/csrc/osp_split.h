@@ -15,7 +15,12 @@
 
 namespace osp {
 
-constexpr int kSplitThreads = 256;
+#ifndef OSP_SPLIT_THREADS
+#define OSP_SPLIT_THREADS 256
+#endif
+constexpr int kSplitThreads = OSP_SPLIT_THREADS;  // workgroup of the stretch split (count and scatter).  (1024 threads with rounds
+                                                  // of 16384 entries -- runs four times as long, one workgroup per CU -- measured: Graph500
+                                                  // scale 20 500 against 505 ms, scale 22 3.97 against 4.06 s; not worth 144 KB of LDS)
 #ifndef OSP_SPLIT_ROW_THREADS
 #define OSP_SPLIT_ROW_THREADS 1024
 #endif
@@ -27,7 +32,10 @@ constexpr int kSplitRowThreads = OSP_SPLIT_ROW_THREADS;  // split_row_kernel's w
 #define OSP_SPLIT_ROW_STRETCH 4096
 #endif
 constexpr int kSplitRowStretch = OSP_SPLIT_ROW_STRETCH;  // ... of split_row_kernel (one workgroup per row)
-constexpr int kSplitStretch = 4096;   // entries a workgroup holds in registers at a time (one round)
+#ifndef OSP_SPLIT_STRETCH
+#define OSP_SPLIT_STRETCH 4096
+#endif
+constexpr int kSplitStretch = OSP_SPLIT_STRETCH;   // entries a workgroup of the stretch split holds in registers at a time (one round)
 #ifndef OSP_SPLIT_JOB_ROUNDS
 #define OSP_SPLIT_JOB_ROUNDS 8
 #endif
