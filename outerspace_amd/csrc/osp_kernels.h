@@ -1615,11 +1615,34 @@ __global__ void parts_scatter_rec_kernel(const int64_t *const *rowptrs, const Pa
                                          const uint64_t *row_off, uint64_t base, Part<T> *stage) {
     const uint64_t r = r0 + ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
     if (r >= r1) return;
+    const unsigned lane = lane_id();
     uint64_t dst = row_off[r] - base;
-    for (int p = 0; p < nparts; p++) {
-        const int64_t b = rowptrs[p][r], e = rowptrs[p][r + 1];
-        for (int64_t i = b + lane_id(); i < e; i += kWave) store_part_words(&stage[dst + (i - b)], load_part_words(&recs[p][i]));
-        dst += (uint64_t)(e - b);
+    // the row's extent in up to 64 parts at a time is fetched by one lane per part (one round trip instead of a chain of
+    // dependent loads per part), then every part's piece is copied with four loads per lane in flight
+    for (int p0 = 0; p0 < nparts; p0 += kWave) {
+        const int np = min(nparts - p0, (int)kWave);
+        int64_t b_l = 0, e_l = 0;
+        if ((int)lane < np) { b_l = rowptrs[p0 + lane][r]; e_l = rowptrs[p0 + lane][r + 1]; }
+        for (int q = 0; q < np; q++) {
+            const uint64_t b = wave_bcast((uint64_t)b_l, (uint32_t)q), len = wave_bcast((uint64_t)(e_l - b_l), (uint32_t)q);
+            const Part<T> *src = recs[p0 + q] + b;
+            Part<T> *out = stage + dst;
+            constexpr int U = 4;
+            for (uint64_t i0 = 0; i0 < len; i0 += (uint64_t)U * kWave) {
+                PartWords<T> w[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint64_t i = i0 + (uint64_t)u * kWave + lane;
+                    w[u] = load_part_words(&src[i < len ? i : 0]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint64_t i = i0 + (uint64_t)u * kWave + lane;
+                    if (i < len) store_part_words(&out[i], w[u]);
+                }
+            }
+            dst += len;
+        }
     }
 }
 
