@@ -586,6 +586,10 @@ def main():
             "gflops": 2 * head["partials"] / (head["ms_per_step"] * 1e-3) / 1e9,
             "partials_per_s": head["partials"] / (head["ms_per_step"] * 1e-3),
             "phases_ms": head["rank0_phases_ms"], "roofline": head["rank0_roofline"], "result_check": head["result_check"],
+            # which decomposition `value` is (the other one, when measured, is under decompositions)
+            "shard": "k" if head is results.get("k") else modes[0],
+            "ms_exchange": head["rank0_phases_ms"].get("ms_exchange"), "ms_final_merge": head["rank0_phases_ms"].get("ms_final_merge"),
+            "bytes_sent_per_rank": head.get("bytes_sent_per_rank"),
             "decompositions": results,
         })
         emit(out)
