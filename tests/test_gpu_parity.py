@@ -814,8 +814,8 @@ def test_panel_boundaries_sweep(ctx, preset, scale, dt):
     rp, ci, va = ref.device_ptrs()
     rowptr, colidx, vals = (_as_tensor(rp, n + 1, "<i8", dev, torch.int64), _as_tensor(ci, nnz, "<i4", dev, torch.int32),
                             _as_tensor(va, nnz, fdt, dev, tdt))
-    rng = np.random.default_rng(99)
-    for it in range(100):
+    rng = np.random.default_rng(int(os.environ.get("OSP_SWEEP_SEED", "99")))
+    for it in range(int(os.environ.get("OSP_SWEEP_ITERS", "100"))):   # (soak runs: OSP_SWEEP_ITERS=1000 OSP_SWEEP_SEED=...)
         cap = int(rng.integers(P // 14, P // 2))
         if it % 2 == 0:
             try:
@@ -859,7 +859,7 @@ def test_slab_and_shard_sweep(ctx, preset, scale):
     n, csr, csc = _bench_module().rmat_device(scale, 16, gen.RMAT_PRESETS[preset], 11, dev, torch.float64)
     torch.cuda.synchronize()
     ptrs = [t.data_ptr() for t in (*csc, *csr)]
-    rng = np.random.default_rng(7)
+    rng = np.random.default_rng(int(os.environ.get("OSP_SWEEP_SEED", "7")))
 
     def unit(**kw):
         r = ctx.spgemm_csc_csr_device(np.float64, n, n, n, ptrs, **kw)
@@ -870,7 +870,7 @@ def test_slab_and_shard_sweep(ctx, preset, scale):
         r.close()
         return out
     done = 0
-    for it in range(40):
+    for it in range(int(os.environ.get("OSP_SWEEP_ITERS", "40"))):
         kw = {}
         if it % 3 != 0:
             k0 = int(rng.integers(0, n - 1))
