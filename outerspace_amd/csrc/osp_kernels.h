@@ -21,7 +21,9 @@ namespace osp {
 // partial products one LDS merge tile holds.  Six per thread of a 256-thread workgroup: the kernel then needs 96
 // registers, so FIVE workgroups run per CU (31 KB of LDS each).  (Measured, tools/bench_merge, 2.7e8 partial
 // products: two workgroups of 512 threads on 3072-entry tiles 4.0 ms, four of 256 on 1536 3.5 ms, five 3.3 ms --
-// independent barrier domains per CU matter more than tile size, although every tile costs a look-back.)
+// independent barrier domains per CU matter more than tile size, although every tile costs a look-back.  Round 2, same
+// tool, level-1 tiles at full fill: 1536 x 256 threads x 5 per CU 2.40 ms; 1792 x 256 x 4 2.65; 2048 x 256 x 4 2.75;
+// 1920 x 320 x 4 3.30; 2304 x 384 x 3 3.96; 3072 x 512 x 2 3.22.)
 template <class T> struct TileCap;
 template <> struct TileCap<float> { static constexpr int value = 1536; };
 template <> struct TileCap<double> { static constexpr int value = 1536; };
@@ -42,7 +44,7 @@ constexpr int kMulBatchAvg = 64;  // ... and at most this many per column on ave
 #define OSP_MUL_TILE_MIN 1024
 #endif
 constexpr int kMulTileMin = OSP_MUL_TILE_MIN;  // B rows from this length on: products numbered in panels of the row (multiply_kernel)
-constexpr int kMulTileW = 128;                 // ... of this many entries
+constexpr int kMulTileW = 128;                 // ... of this many entries (256: 77 registers, slower everywhere; 64: slower at Graph500 skew)
 
 // One staged partial product: 4-byte column + value, packed (12 B for f64, 8 B for f32).  Array of
 // records rather than two arrays: a chunk is then ONE contiguous byte range, which halves the number
