@@ -541,10 +541,13 @@ def main():
             # this rank's operands: ONLY its columns of A and rows of B
             slab = D.slice_k_slab(csc, csr, k_bounds[rank], k_bounds[rank + 1])
             torch.cuda.synchronize()   # (sliced by torch kernels; the library works on a stream of its own)
+            # the form of the exchange is a property of the slab: agreed on once, outside the timed steps
+            k_exchange = D.agree_k_exchange(ctx, np_dtype, slab, dist, args.k_exchange, args.dist_backend == "gloo")
 
             def step(checksum=False):
                 return D.spgemm_k_sharded(ctx, np_dtype, n, n, slab, dist, rank, world, partial_capacity=args.partial_capacity,
-                                          stage_through_host=args.dist_backend == "gloo", checksum=checksum, exchange=args.k_exchange)
+                                          stage_through_host=args.dist_backend == "gloo", checksum=checksum, exchange=k_exchange,
+                                          agreed=True)
         else:
             ptrs = [t.data_ptr() for t in (*csc, *csr)]
 

@@ -105,6 +105,9 @@ typedef struct osp_result_info {
     uint64_t split_partials;    /* partial products those launches moved (lower bound: heavy_partials minus the
                                    capacity of the stretch-split jobs) */
     uint64_t dense_segments;    /* over-long segments of hub rows reduced by dense accumulation (no sort) */
+    uint32_t rank_atomic;       /* 1: stable radix ranks from the return order of LDS atomics, 0: from ballot matching   */
+    uint32_t dense_atomic;      /* 1: dense segments summed by LDS floating-point atomics, 0: by ballot ranks and rounds */
+                                /* (both variants are exact; a context picks them by a self-test)         */
 } osp_result_info_t;
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -219,6 +222,8 @@ int osp_result_partials(osp_result_t r, const int64_t **rowptr, const void **rec
 /*
  * Sum `nparts` collections of records of identical shape (M rows, columns < N) into one CSR: rowptrs[p][M+1] offsets in
  * records, records[p] packed {uint32 col; T val}; rows need be neither sorted nor free of duplicates.
+ * Precondition: offsets monotone from 0, every column < N.  With cfg->validate != 0 both are checked on the device first
+ * (OSP_ERR_ARG / OSP_ERR_RANGE); without it a violation indexes out of bounds on the device.
  */
 int osp_merge_record_parts(osp_context_t ctx, osp_dtype_t dtype, uint64_t M, uint64_t N, int nparts,
                            const int64_t *const *rowptrs, const void *const *records, osp_memspace_t space,

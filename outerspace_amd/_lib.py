@@ -44,7 +44,7 @@ class ResultInfo(C.Structure):
                 ("ms_multiply_kernel", C.c_float), ("ms_merge_kernel", C.c_float), ("ms_ingest", C.c_float),
                 ("multiply_launches", C.c_uint32), ("merge_launches", C.c_uint32), ("dtype", C.c_int),
                 ("ms_split_kernel", C.c_float), ("split_launches", C.c_uint32), ("split_partials", C.c_uint64),
-                ("dense_segments", C.c_uint64)]
+                ("dense_segments", C.c_uint64), ("rank_atomic", C.c_uint32), ("dense_atomic", C.c_uint32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

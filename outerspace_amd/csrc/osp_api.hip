@@ -364,9 +364,14 @@ struct Pinned {
         half = want;
     }
 };
+// One staging object per (thread, device): its events belong to the device that was current when they were created,
+// and recording them on another device's stream fails with "invalid resource handle" -- a thread may own contexts on
+// several devices (the multi-GPU entry point does).
 static Pinned &pinned_buffer() {
-    static thread_local Pinned b;  // lives as long as the thread; at most 32 MB
-    return b;
+    static thread_local std::map<int, Pinned> per_device;  // lives as long as the thread; at most 32 MB per device
+    int dev = 0;
+    OSP_HIP(hipGetDevice(&dev));
+    return per_device[dev];
 }
 static void copy_h2d(void *dst, const void *src, size_t bytes, hipStream_t s) {
     if (!bytes) return;
@@ -1347,6 +1352,17 @@ static void merge_record_parts_impl(Context *ctx, Result *res, uint64_t M, uint6
         nnz_in += (uint64_t)n;
     }
     res->info.nnz_a = nnz_in;
+    if (cfg.validate) {
+        // offsets monotone from 0 to the record count, columns below N: what the split and dense paths index with
+        uint32_t *flags = sc.get<uint32_t>(1);
+        OSP_HIP(hipMemsetAsync(flags, 0, sizeof(uint32_t), s));
+        for (int p = 0; p < nparts; p++) {
+            const uint64_t n = (uint64_t)((space == OSP_HOST) ? rowptrs[p][M] : d2h(rp[p] + M, s));
+            validate_ptr_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(rp[p], M, n, flags);
+            if (n) validate_record_cols_kernel<T><<<grid_for(n, 256), 256, 0, s>>>(rc[p], n, N, flags);
+        }
+        check_flags(d2h(flags, s), "record parts");
+    }
     const int64_t **d_rp = (const int64_t **)sc.get<void *>(nparts);
     const Part<T> **d_rc = (const Part<T> **)sc.get<void *>(nparts);
     copy_h2d(d_rp, rp.data(), nparts * sizeof(void *), s);
@@ -1373,6 +1389,12 @@ static void merge_record_parts_impl(Context *ctx, Result *res, uint64_t M, uint6
     res->info.ms_compact = tm.total(PH_COMPACT);
     res->info.ms_merge_kernel = tm.total(PH_MERGE_K);
     res->info.ms_split_kernel = tm.total(PH_SPLIT_K);
+}
+
+// which of the two exact variants of the order-sensitive steps this context runs (visible in every result)
+static void note_variants(const Context *ctx, Result *res) {
+    res->info.rank_atomic = ctx->rank_atomic ? 1u : 0u;
+    res->info.dense_atomic = ctx->dense_atomic[res->dtype == OSP_F64] ? 1u : 0u;
 }
 
 static void destroy_result(Result *r) {
@@ -1534,6 +1556,7 @@ int osp_spgemm_csc_csr(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, uint64
     res->ctx = ctx;
     res->dtype = dtype;
     res->info.M = M; res->info.K = K; res->info.N = N; res->info.dtype = dtype;
+    note_variants(ctx, res);
     try {
         OSP_HIP(hipSetDevice(ctx->device));
         if (dtype == OSP_F32)
@@ -1570,6 +1593,7 @@ int osp_spgemm_csc_csr_aos(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, ui
     res->ctx = ctx;
     res->dtype = dtype;
     res->info.M = M; res->info.K = K; res->info.N = N; res->info.dtype = dtype;
+    note_variants(ctx, res);
     try {
         OSP_HIP(hipSetDevice(ctx->device));
         if (dtype == OSP_F32) spgemm_aos_impl<float>(ctx, res, M, K, N, a_pos, a_data, b_pos, b_data, space, cfg);
@@ -1604,6 +1628,7 @@ int osp_spgemm_csc_csr_panels(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M,
     res->ctx = ctx;
     res->dtype = dtype;
     res->info.M = M; res->info.K = K; res->info.N = N; res->info.dtype = dtype;
+    note_variants(ctx, res);
     const PanelSink sink{fn, user};
     int st = OSP_OK;
     try {
@@ -1643,6 +1668,7 @@ int osp_spgemm_coo(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, uint64_t K
     res->ctx = ctx;
     res->dtype = dtype;
     res->info.M = M; res->info.K = K; res->info.N = N; res->info.dtype = dtype;
+    note_variants(ctx, res);
     try {
         OSP_HIP(hipSetDevice(ctx->device));
         if (dtype == OSP_F32)
@@ -1679,6 +1705,7 @@ int osp_merge_csr_parts(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, uint6
     res->ctx = ctx;
     res->dtype = dtype;
     res->info.M = M; res->info.N = N; res->info.dtype = dtype;
+    note_variants(ctx, res);
     try {
         OSP_HIP(hipSetDevice(ctx->device));
         if (dtype == OSP_F32) merge_parts_impl<float>(ctx, res, M, N, nparts, rowptrs, colidxs, valss, space, cfg);
@@ -1711,6 +1738,7 @@ int osp_spgemm_partials(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, uint6
     res->ctx = ctx;
     res->dtype = dtype;
     res->info.M = M; res->info.K = K; res->info.N = N; res->info.dtype = dtype;
+    note_variants(ctx, res);
     try {
         OSP_HIP(hipSetDevice(ctx->device));
         if (dtype == OSP_F32)
@@ -1755,6 +1783,7 @@ int osp_merge_record_parts(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, ui
     res->ctx = ctx;
     res->dtype = dtype;
     res->info.M = M; res->info.N = N; res->info.dtype = dtype;
+    note_variants(ctx, res);
     try {
         OSP_HIP(hipSetDevice(ctx->device));
         if (dtype == OSP_F32) merge_record_parts_impl<float>(ctx, res, M, N, nparts, rowptrs, records, space, cfg);

@@ -150,6 +150,13 @@ __global__ void validate_idx_kernel(const int64_t *ptr, const uint32_t *idx, uin
     }
 }
 
+// columns of packed records (osp_merge_record_parts with cfg.validate): every one below its dimension
+template <class T>
+__global__ void validate_record_cols_kernel(const Part<T> *rec, uint64_t n, uint64_t bound, uint32_t *flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (uint64_t)rec[i].col >= bound) atomicOr(flags, kFlagRange);
+}
+
 // ---- symbolic ----------------------------------------------------------------------------------
 // For every non-zero e of A (CSC order, column k in [k0,k1)): key[e] = its row, payload = e,
 // w[e] = nnz(B[k,:]) = the length of its chunk.

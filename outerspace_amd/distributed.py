@@ -146,19 +146,45 @@ def exchange_partial_csr(rowptr, colidx, vals, dist, world, group=None, ncols=No
     return rb, parts
 
 
+class LocalDoesNotFit(Exception):
+    """Raised by a ``local_product`` whose result does not fit this rank's device in the form agreed on."""
+
+
 def k_sharded_product(local_product, merge_parts, k_bounds, dist, world, group=None, sync=None, ncols=None, alloc=None,
-                      after_exchange=None, stats=None, widths=(1, 1)):
+                      after_exchange=None, stats=None, widths=(1, 1), fallback=None, flag_device="cpu"):
     """Generic driver: local slab product -> exchange -> local merge.
 
     local_product(k0, k1) -> (rowptr, colidx, vals) tensors (partial CSR over all rows)
     merge_parts(nrows, parts) -> (rowptr, colidx, vals) of the summed CSR
     after_exchange() (optional) runs once the exchange has completed: the place to release the local partial CSR before
     the final merge allocates (at 2 GPUs and scale 22 both do not fit side by side).
-    Returns dict(row_bounds, rowptr, colidx, vals, seconds=(local, exchange, merge)).
+    fallback (optional) = dict(local_product=, merge_parts=, ncols=, widths=): a second form of the same product that needs
+    less memory.  When it is given, every rank reports after its local product whether that one raised
+    ``LocalDoesNotFit`` (one all-reduce, before any other collective), and if ANY rank did, ALL ranks drop what they have
+    and redo the local step in the fallback form -- the form of the exchange (payload widths, count types, merge function)
+    is a property of the whole job, never of one rank.  Without it a ``LocalDoesNotFit`` simply propagates.
+    Returns dict(row_bounds, rowptr, colidx, vals, seconds=(local, exchange, merge), fell_back).
     """
     rank = dist.get_rank(group)
     t0 = time.perf_counter()
-    local = local_product(k_bounds[rank], k_bounds[rank + 1])   # (rowptr, colidx, vals) or (rowptr, packed records)
+    fell_back = False
+    if fallback is None:
+        local = local_product(k_bounds[rank], k_bounds[rank + 1])   # (rowptr, colidx, vals) or (rowptr, packed records)
+    else:
+        local, failed = None, 0
+        try:
+            local = local_product(k_bounds[rank], k_bounds[rank + 1])
+        except LocalDoesNotFit:
+            failed = 1
+        flag = torch.tensor([failed], dtype=torch.int32, device=flag_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if int(flag[0]):
+            del local
+            if fallback.get("discard"):
+                fallback["discard"]()   # whatever the first attempt left behind on this rank
+            local = fallback["local_product"](k_bounds[rank], k_bounds[rank + 1])
+            merge_parts, ncols, widths = fallback["merge_parts"], fallback.get("ncols"), fallback.get("widths", (1, 1))
+            fell_back = True
     rowptr, colidx, vals = local if len(local) == 3 else (local[0], local[1], None)
     if sync:
         sync()
@@ -174,7 +200,7 @@ def k_sharded_product(local_product, merge_parts, k_bounds, dist, world, group=N
     if sync:
         sync()
     t3 = time.perf_counter()
-    return dict(row_bounds=rb, rowptr=out[0], colidx=out[1], vals=out[2], seconds=(t1 - t0, t2 - t1, t3 - t2))
+    return dict(row_bounds=rb, rowptr=out[0], colidx=out[1], vals=out[2], seconds=(t1 - t0, t2 - t1, t3 - t2), fell_back=fell_back)
 
 
 class _DevArray:
@@ -210,8 +236,20 @@ def slice_k_slab(csc, csr, k0, k1):
     return k1 - k0, cut(csc), cut(csr)
 
 
+def agree_k_exchange(ctx, np_dtype, slab, dist, exchange="raw", stage_through_host=False):
+    """The form of the exchange every rank will use, decided ONCE per slab (bench.py calls it beside ``slice_k_slab``,
+    outside the timed steps): "raw" only if every rank expects its records to fit (``_records_fit``: a reduction over the
+    slab, a host sync and a memory query -- not something to repeat in every step)."""
+    if exchange != "raw":
+        return exchange
+    _, csc, csr = slab
+    need = torch.tensor([1 if _records_fit(ctx, csc, csr, np_dtype) else 0], device="cpu" if stage_through_host else csc[0].device)
+    dist.all_reduce(need, op=dist.ReduceOp.MIN)
+    return "raw" if int(need[0]) else "merged"
+
+
 def spgemm_k_sharded(ctx, np_dtype, M, N, slab, dist, rank, world, partial_capacity=0, stage_through_host=False, checksum=False,
-                     fetch=False, exchange="raw"):
+                     fetch=False, exchange="raw", agreed=False, _fail_raw_on_rank=None):
     """The GPU instantiation used by bench.py.  slab = slice_k_slab(...) of THIS rank: (K', csc', csr') CUDA tensors.
     Returns an info dict (the local product's counters plus the exchange / final-merge figures); fetch=True adds
     info["final_csr"] = this rank's rows of C as host arrays (rowptr, colidx, vals) -- tests only.
@@ -242,20 +280,27 @@ def spgemm_k_sharded(ctx, np_dtype, M, N, slab, dist, rank, world, partial_capac
     words = 1 + np.dtype(np_dtype).itemsize // 4   # 32-bit words per packed record
     mode = {"exchange": exchange}
 
-    def local_product(_k0, _k1):
-        if mode["exchange"] == "raw":
-            try:
-                res = ctx.spgemm_partials_device(np_dtype, M, Ks, N, ptrs)
-            except _OspError as e:
-                if e.status != 3:   # anything but "does not fit": a real error
-                    raise
-                mode["exchange"] = "merged"
-        if mode["exchange"] == "raw":
-            keep["local"] = res
-            keep["local_info"] = dict(res.info)
-            rp, rec = res.partials_ptrs()
-            out = (_as_tensor(rp, M + 1, "<i8", device, torch.int64), _as_tensor(rec, res.nnz * words, "<i4", device, torch.int32))
-            return tuple(t.cpu() for t in out) if stage_through_host else out
+    def local_raw(_k0, _k1):
+        try:
+            if _fail_raw_on_rank is not None and rank == _fail_raw_on_rank:   # tests: the allocation failure of ONE rank
+                raise _OspError(3, "forced allocation failure (test)")
+            res = ctx.spgemm_partials_device(np_dtype, M, Ks, N, ptrs)
+        except _OspError as e:
+            if e.status != 3:   # anything but "does not fit": a real error
+                raise
+            raise LocalDoesNotFit(str(e))
+        keep["local"] = res
+        keep["local_info"] = dict(res.info)
+        rp, rec = res.partials_ptrs()
+        out = (_as_tensor(rp, M + 1, "<i8", device, torch.int64), _as_tensor(rec, res.nnz * words, "<i4", device, torch.int32))
+        return tuple(t.cpu() for t in out) if stage_through_host else out
+
+    def discard_raw():
+        if "local" in keep:
+            keep.pop("local").close()
+        mode["exchange"] = "merged"
+
+    def local_merged(_k0, _k1):
         res = ctx.spgemm_csc_csr_device(np_dtype, M, Ks, N, ptrs, validate=False, partial_capacity=partial_capacity)
         keep["local"] = res
         keep["local_info"] = dict(res.info)
@@ -274,32 +319,44 @@ def spgemm_k_sharded(ctx, np_dtype, M, N, slab, dist, rank, world, partial_capac
     def release_local():
         keep.pop("local").close()
 
-    def merge_parts(nrows, parts):
+    def landed(parts):
         if stage_through_host:
             parts = [tuple(t.to(device) for t in p) for p in parts]
             keep["parts"] = parts
         torch.cuda.current_stream().synchronize()  # received data must have landed
-        if mode["exchange"] == "raw":
-            res = ctx.merge_record_parts_device(np_dtype, nrows, N, [(r.data_ptr(), c.data_ptr()) for r, c in parts],
-                                                partial_capacity=partial_capacity)
-        else:
-            res = ctx.merge_csr_parts_device(np_dtype, nrows, N, [(r.data_ptr(), c.data_ptr(), v.data_ptr()) for r, c, v in parts],
-                                             partial_capacity=partial_capacity)
+        return parts
+
+    def merge_raw(nrows, parts):
+        parts = landed(parts)
+        res = ctx.merge_record_parts_device(np_dtype, nrows, N, [(r.data_ptr(), c.data_ptr()) for r, c in parts],
+                                            partial_capacity=partial_capacity)
+        keep["final"] = res
+        return res.device_ptrs()
+
+    def merge_merged(nrows, parts):
+        parts = landed(parts)
+        res = ctx.merge_csr_parts_device(np_dtype, nrows, N, [(r.data_ptr(), c.data_ptr(), v.data_ptr()) for r, c, v in parts],
+                                         partial_capacity=partial_capacity)
         keep["final"] = res
         return res.device_ptrs()
 
     try:
-        # every rank must take the same form of exchange: agree on it before the first collective (a rank whose records do
-        # not fit turns all of them to the merged form)
+        # Every rank must take the same form of exchange.  Two agreements: BEFORE the product, an estimate (a rank whose
+        # records are not expected to fit turns all of them to the merged form; `agreed=True`: the caller has done that once
+        # for this slab with agree_k_exchange); AFTER the local product, the fact -- a rank whose allocation failed all the
+        # same makes every rank redo the step in the merged form (k_sharded_product's fallback), instead of leaving the
+        # others in a collective it never joins.
+        if not agreed:
+            mode["exchange"] = agree_k_exchange(ctx, np_dtype, slab, dist, mode["exchange"], stage_through_host)
+        k_bounds = [0] * (rank + 1) + [Ks] * (world - rank)
+        common = dict(sync=torch.cuda.synchronize, alloc=pool_alloc, after_exchange=release_local, stats=stats,
+                      flag_device="cpu" if stage_through_host else device)
         if mode["exchange"] == "raw":
-            need = torch.tensor([1 if _records_fit(ctx, csc, csr, np_dtype) else 0], device="cpu" if stage_through_host else device)
-            dist.all_reduce(need, op=dist.ReduceOp.MIN)
-            if int(need[0]) == 0:
-                mode["exchange"] = "merged"
-        raw = mode["exchange"] == "raw"
-        out = k_sharded_product(local_product, merge_parts, [0] * (rank + 1) + [Ks] * (world - rank), dist, world,
-                                sync=torch.cuda.synchronize, ncols=None if raw else N, alloc=pool_alloc, after_exchange=release_local,
-                                stats=stats, widths=(words,) if raw else (1, 1))
+            out = k_sharded_product(local_raw, merge_raw, k_bounds, dist, world, ncols=None, widths=(words,),
+                                    fallback=dict(local_product=local_merged, merge_parts=merge_merged, ncols=N, widths=(1, 1),
+                                                  discard=discard_raw), **common)
+        else:
+            out = k_sharded_product(local_merged, merge_merged, k_bounds, dist, world, ncols=N, widths=(1, 1), **common)
         info = keep["local_info"]
         fin = keep["final"].info
         tot = torch.tensor([fin["nnz_c"], info["partials"]], device="cpu" if stage_through_host else device, dtype=torch.int64)

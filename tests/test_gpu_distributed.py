@@ -40,10 +40,11 @@ def _rank_main(rank, world, port, preset, scale, out_dir):
             slab = D.slice_k_slab(csc, csr, kb[rank], kb[rank + 1])
             assert slab[0] == kb[rank + 1] - kb[rank] and slab[1][0].numel() == slab[0] + 1 and int(slab[1][0][0]) == 0
             del csc, csr   # from here on the rank holds nothing but its slab
-            for tag, exch in (("k", "raw"), ("m", "merged")):
+            # "f": rank 1's records "do not fit" after the ranks agreed on the raw exchange -- both must end up merged
+            for tag, exch, fail in (("k", "raw", None), ("m", "merged", None), ("f", "raw", 1)):
                 info = D.spgemm_k_sharded(ctx, np.float64, n, n, slab, dist, rank, world, stage_through_host=True, checksum=True,
-                                          fetch=True, exchange=exch)
-                assert info["exchange"] == exch
+                                          fetch=True, exchange=exch, _fail_raw_on_rank=fail)
+                assert info["exchange"] == ("merged" if fail is not None else exch)
                 rb = info["row_bounds"]
                 np.savez(os.path.join(out_dir, f"{tag}{rank}.npz"), r0=rb[rank], r1=rb[rank + 1], rowptr=info["final_csr"][0],
                          colidx=info["final_csr"][1], vals=info["final_csr"][2], nnz_global=info["nnz_c_global"],
@@ -69,7 +70,7 @@ def test_two_rank_processes_share_one_gpu(tmp_path, port, preset, scale):
     mp.spawn(_rank_main, args=(world, _free_port(), preset, scale, str(tmp_path)), nprocs=world, join=True)
     n, rows, cols, vals = gen.rmat_coo(scale, 12, preset, seed=21)
     want = port.spgemm(n, n, n, *S.coo_to_csc(n, rows, cols, vals), *S.coo_to_csr(n, rows, cols, vals))
-    for mode in ("k", "m", "r"):
+    for mode in ("k", "m", "f", "r"):
         got = [np.load(tmp_path / f"{mode}{r}.npz") for r in range(world)]
         assert int(got[0]["r0"]) == 0 and int(got[0]["r1"]) == int(got[1]["r0"]) and int(got[1]["r1"]) == n
         for g in got:
@@ -85,7 +86,7 @@ def test_two_rank_processes_share_one_gpu(tmp_path, port, preset, scale):
                 assert np.allclose(g["vals"], want["vals"][lo:hi], rtol=1e-12, atol=0)     # slab sums re-associate
             assert int(g["nnz_global"]) == len(want["colidx"]) and int(g["partials_global"]) == want["partials"]
             assert np.isclose(float(g["val_sum"]), want["vals"].sum(), rtol=1e-12)
-        if mode in ("k", "m"):
+        if mode in ("k", "m", "f"):
             # each rank computed only its slab (about half the partial products) and sent about half of its partial CSR
             assert sum(int(g["local_partials"]) for g in got) == want["partials"]
             assert all(0 < int(g["bytes_sent"]) for g in got)
