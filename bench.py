@@ -51,7 +51,17 @@ def parse():
                     help="R-MAT (a,b,c,d): mild=(.45,.22,.22,.11) [default: skewed, and C still fits one GPU's HBM] | "
                          "uniform=(.25,.25,.25,.25) | g500=(.57,.19,.19,.05) [scale-22 needs ~840 GB for C] | a,b,c,d")
     ap.add_argument("--workload", default="rmat", choices=["rmat", "webgoogle"],
-                    help="webgoogle = BASELINE configs[1] shape (916428 vertices, ~5.1 M pattern non-zeros, power-law degrees)")
+                    help="webgoogle = BASELINE configs[1]: the real SuiteSparse file when --a-mtx names it (or $OSP_WEBGOOGLE_MTX / "
+                         "./web-Google.mtx exist), else its shape (916428 vertices, ~5.1 M pattern non-zeros, power-law degrees)")
+    ap.add_argument("--a-mtx", default=None, help="MatrixMarket file of A: the product of real files instead of a synthetic matrix "
+                                                  "(the reference CLI's call shape, SimSpGEMM.cpp:819-825)")
+    ap.add_argument("--b-mtx", default=None, help="MatrixMarket file of B (default: the file of A)")
+    ap.add_argument("--no-transpose-b", action="store_true",
+                    help="with --a-mtx: multiply A * B; default A * B^T, as the reference CLI does (SimSpGEMM.cpp:852-856)")
+    ap.add_argument("--ingest", type=int, default=1,
+                    help="N=1: report the ingest beside the product -- host parse of the .mtx text (a bounded sample file for "
+                         "synthetic workloads) and COO -> CSC/CSR on the device, next to the reference's Read Matrix / COO2CSR timers")
+    ap.add_argument("--ingest-sample", type=int, default=4_000_000, help="entries of the sample file the parsers are timed on")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--dtype", default="f64", choices=["f32", "f64"])
     ap.add_argument("--partial-capacity", type=int, default=0)
@@ -180,6 +190,138 @@ def webgoogle_device(seed, device, dtype):
     vals = torch.ones(rows.numel(), device=device, dtype=dtype)
     csr, csc = _compress(n, rows, cols, vals, device)
     return n, csr, csc
+
+
+def mtx_device(path_a, path_b, transpose_b, device, dtype, ingest):
+    """Operands from MatrixMarket files (host parse by the library's reader, osp_mtx_read = readcoo): CSC(A) and CSR(B) --
+    B transposed first unless told otherwise, as the reference's main() does -- as torch tensors on the device.  Both are
+    embedded in n x n with n = the largest dimension (empty rows / columns do not change the product), which is what the
+    rest of this benchmark is written for.  Parse times go to `ingest`."""
+    import torch
+    from outerspace_amd import spgemm as S
+
+    def read(path):
+        t0 = time.perf_counter()
+        nr, nc, r, c, v = S.read_mtx(path)
+        dt = time.perf_counter() - t0
+        ingest.setdefault("host_parse", []).append(
+            {"file": os.path.basename(path), "MB": os.path.getsize(path) / 1e6, "entries": int(len(r)), "seconds": dt,
+             "M_entries_per_s": len(r) / dt / 1e6, "MB_per_s": os.path.getsize(path) / 1e6 / dt,
+             "threads": os.environ.get("OSP_PARSE_THREADS", f"auto (<= 32, host has {os.cpu_count()} cores)")})
+        return nr, nc, r, c, v
+    a = read(path_a)
+    b = a if (path_b is None or path_b == path_a) else read(path_b)
+    b_nr, b_nc, b_r, b_c = (b[1], b[0], b[3], b[2]) if transpose_b else (b[0], b[1], b[2], b[3])
+    if a[1] != b_nr:
+        raise SystemExit(f"inner dimensions differ: A is {a[0]}x{a[1]}, B{'^T' if transpose_b else ''} is {b_nr}x{b_nc}")
+    n = int(max(a[0], a[1], b_nc))
+
+    def compress(rows, cols, vals, by_col):
+        rows = torch.from_numpy(rows.astype(np.int64)).to(device)
+        cols = torch.from_numpy(cols.astype(np.int64)).to(device)
+        vals = torch.from_numpy(vals).to(device, dtype)
+        seg, inner = (cols, rows) if by_col else (rows, cols)
+        key = seg * n + inner
+        order = torch.argsort(key)
+        key = key[order]
+        if key.numel() > 1 and bool((key[1:] == key[:-1]).any()):
+            raise SystemExit("duplicate coordinate in the input (the reference throws 233, SimSpGEMM.cpp:49)")
+        ptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+        ptr[1:] = torch.cumsum(torch.bincount(seg, minlength=n), 0)
+        return (ptr, inner[order].to(torch.int32).contiguous(), vals[order].contiguous())
+    csc = compress(a[2], a[3], a[4], True)
+    csr = compress(b_r, b_c, b[4], False)
+    return n, csr, csc, (a[0], a[1], b_nc)
+
+
+def ingest_report(ctx, n, csr, csc, np_dtype, device, args, ingest, with_reference):
+    """The ingest beside the product (reference: TIMER("Read Matrix") SimSpGEMM.cpp:844-850 = readcoo
+    :55-100, TIMER("COO2CSR") :876-880 = coo2csr :102-152).
+      device  COO -> CSC(A) / CSR(B) of the FULL operands by osp_spgemm_coo (two stable radix sorts and the duplicate check
+              per operand), priced against its model of ~100 B per non-zero;
+      host    the library's .mtx reader on the real files, or -- synthetic workloads -- on a sample file of
+              --ingest-sample entries written for the purpose, with the compiled reference's readcoo / coo2csr timed on the
+              same sample (one core: it is single-threaded by construction)."""
+    import tempfile
+    import torch
+    from outerspace_amd import spgemm as S
+    nnz_a, nnz_b = int(csc[0][-1]), int(csr[0][-1])
+    ar = csc[1]
+    ac = torch.repeat_interleave(torch.arange(n, device=device, dtype=torch.int32), (csc[0][1:] - csc[0][:-1]))
+    br = torch.repeat_interleave(torch.arange(n, device=device, dtype=torch.int32), (csr[0][1:] - csr[0][:-1]))
+    torch.cuda.synchronize()
+    res = ctx.spgemm_coo_device(np_dtype, n, n, n, nnz_a, (ar.data_ptr(), ac.data_ptr(), csc[2].data_ptr()),
+                                nnz_b, (br.data_ptr(), csr[1].data_ptr(), csr[2].data_ptr()))
+    ms = float(res.info["ms_ingest"])
+    res.close()
+    model = 100.0 * (nnz_a + nnz_b)   # DESIGN.md section 3: ~100 B per non-zero (keys, payloads and histograms of the passes)
+    ingest["device_coo_to_compressed"] = {"ms": ms, "nnz_a": nnz_a, "nnz_b": nnz_b, "model_bytes": model,
+                                          "GBps": model / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                                          "frac_of_peak": model / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0,
+                                          "M_nnz_per_s": (nnz_a + nnz_b) / (ms * 1e-3) / 1e6 if ms > 0 else 0.0}
+    del ac, br
+    sample = None
+    if "host_parse" not in ingest:
+        # synthetic operands: a sample of A in file form (the rows at the head of the matrix), as scipy.io.mmwrite lays it out
+        k = min(nnz_a, args.ingest_sample)
+        rp = csr[0].cpu().numpy()
+        rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp))[:k] + 1
+        cols = csr[1][:k].cpu().numpy().astype(np.int64) + 1
+        vals = csr[2][:k].cpu().numpy().astype(np.float64)
+        tmp = tempfile.mkdtemp(prefix="osp_ingest_")
+        sample = os.path.join(tmp, "sample.mtx")
+        with open(sample, "w") as f:
+            f.write(f"%%MatrixMarket matrix coordinate real general\n%\n{n} {n} {k}\n")
+        try:
+            import pandas as pd
+            pd.DataFrame({"r": rows, "c": cols, "v": vals}).to_csv(sample, sep=" ", header=False, index=False, mode="a", float_format="%.17g")
+        except ImportError:
+            with open(sample, "a") as f:
+                np.savetxt(f, np.stack([rows, cols, vals], 1), fmt="%d %d %.17g")
+        t0 = time.perf_counter()
+        got = S.read_mtx(sample)
+        dt = time.perf_counter() - t0
+        assert len(got[2]) == k and np.array_equal(got[2], (rows - 1).astype(np.uint32)) and np.array_equal(got[4], vals)
+        mb = os.path.getsize(sample) / 1e6
+        ingest["host_parse"] = [{"file": f"sample of A: its first {k} entries written as .mtx text", "MB": mb, "entries": int(k), "seconds": dt,
+                                 "M_entries_per_s": k / dt / 1e6, "MB_per_s": mb / dt,
+                                 "threads": os.environ.get("OSP_PARSE_THREADS", f"auto (<= 32, host has {os.cpu_count()} cores)"),
+                                 "full_operand_extrapolated_s": nnz_a / (k / dt)}]
+    if with_reference:
+        from oracle import oracle   # baseline only
+        if oracle.have_ref() and sample is not None:
+            r = oracle.ref(np_dtype)
+            t0 = time.perf_counter()
+            nr, nc, rr, cc, vv = r.readcoo(sample)
+            t1 = time.perf_counter()
+            r.coo2csr(True, n, rr, cc, vv)
+            r.coo2csr(False, n, rr, cc, vv)
+            t2 = time.perf_counter()
+            k = len(rr)
+            ingest["reference_on_the_same_sample"] = {"entries": int(k), "read_matrix_s": t1 - t0, "coo2csr_x2_s": t2 - t1, "cores": 1,
+                                                      "M_entries_per_s_read": k / (t1 - t0) / 1e6,
+                                                      "M_entries_per_s_coo2csr": 2 * k / (t2 - t1) / 1e6}
+    if sample is not None:
+        os.remove(sample)
+        os.rmdir(os.path.dirname(sample))
+    return ingest
+
+
+def webgoogle_file():
+    """The real SuiteSparse web-Google file, when the box has it (it is not in the repository: no network here)."""
+    for cand in (os.environ.get("OSP_WEBGOOGLE_MTX"), os.path.join(ROOT, "web-Google.mtx"), "web-Google.mtx"):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def webgoogle_operands(seed, device, dtype):
+    """configs[1]: the real file's self-product when it is present, else the synthetic shape."""
+    path = webgoogle_file()
+    if path:
+        n, csr, csc, _ = mtx_device(path, None, False, device, dtype, {})
+        return n, csr, csc
+    return webgoogle_device(seed, device, dtype)
 
 
 def expected_value_sum(n, csr, csc, device):
@@ -318,6 +460,14 @@ def kernel_roofline(infos, n, E):
         nbytes = 3.0 * E * minfo["split_partials"] / nsp
         kernels["split_row_kernel"] = {"algorithmic_bytes_per_launch": nbytes, "ms_per_launch": per, "launches_per_step": nsp,
                                        "GBps": (nbytes / (per * 1e-3) / 1e9) if per > 0 else 0.0}
+    if minfo.get("direct_plan_launches"):
+        # the plan of the direct rows: B's column indices of every such row read twice (histogram, cells); what it writes
+        # (one word per chunk and range) is small beside that
+        npl = minfo["direct_plan_launches"]
+        per = mean("ms_direct_plan_kernel", minfos) / npl
+        nbytes = 2.0 * 4 * minfo["direct_partials"] / npl
+        kernels["direct_plan_kernel"] = {"algorithmic_bytes_per_launch": nbytes, "ms_per_launch": per, "launches_per_step": npl,
+                                         "GBps": (nbytes / (per * 1e-3) / 1e9) if per > 0 else 0.0}
     for k in kernels.values():
         k["frac_of_peak"] = k["GBps"] / HBM_PEAK_GBS
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
@@ -431,7 +581,19 @@ def main():
     np_dtype = np.float64 if args.dtype == "f64" else np.float32
     E = 4 + np.dtype(np_dtype).itemsize
 
-    if args.workload == "webgoogle":
+    ingest = {}
+    data_kind = "synthetic"
+    a_mtx = args.a_mtx
+    if a_mtx is None and args.workload == "webgoogle" and webgoogle_file():   # configs[1]: the real file when the box has it
+        a_mtx = webgoogle_file()
+        args.no_transpose_b = True   # the self-product A * A of configs[1]
+    if a_mtx is not None:
+        n, csr, csc, dims = mtx_device(a_mtx, args.b_mtx, not args.no_transpose_b, device, tdtype, ingest)
+        bname = os.path.basename(args.b_mtx or a_mtx)
+        workload_name = (f"files: {os.path.basename(a_mtx)} ({dims[0]}x{dims[1]}) * {bname}{'' if args.no_transpose_b else '^T'} "
+                         f"-> {dims[0]}x{dims[2]}, CSC x CSR -> CSR")
+        data_kind = "files"
+    elif args.workload == "webgoogle":
         n, csr, csc = webgoogle_device(args.seed, device, tdtype)
         workload_name = "web-Google-shaped synthetic pattern matrix (916428 vertices, power-law degrees), self-product"
     else:
@@ -452,7 +614,7 @@ def main():
         return float(t[0])
 
     out = {"metric": "spgemm_output_nnz_per_s", "unit": "nnz/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic"}
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": data_kind}
 
     if not use_dist:
         # ================================================= one GPU =================================================
@@ -474,14 +636,18 @@ def main():
             "whole_product": {"algorithmic_bytes": alg_total, "GBps": alg_total / (ms_step * 1e-3) / 1e9,
                               "frac_of_peak": alg_total / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "phases_ms": {k: float(np.mean([i[k] for i in infos])) for k in ("ms_symbolic", "ms_multiply", "ms_merge", "ms_compact", "ms_total")},
-            "panels": info["panels"], "long_rows_split": info["heavy_rows"], "long_row_partials": info["heavy_partials"],
+            "panels": info["panels"], "long_rows": info["heavy_rows"], "long_row_partials": info["heavy_partials"],
+            # long rows the multiply wrote straight into their column ranges (no split pass), and the ones split afterwards
+            "long_rows_direct": info["direct_rows"], "long_row_partials_direct": info["direct_partials"],
+            "long_row_partials_split_by_one_workgroup": info["split_partials"],
             "segments_global_sorted": info["sorted_segments"], "segment_partials_global_sorted": info["sorted_partials"],
             "roofline": roof,
             # per-step device times (ms): how much the numbers above move from one product to the next
             "steps_ms": {"total": [round(i["ms_total"], 2) for i in infos],
                          "multiply_kernel": [round(i["ms_multiply_kernel"], 2) for i in infos],
                          "merge_kernel": [round(i["ms_merge_kernel"], 2) for i in infos],
-                         "split_row_kernel": [round(i["ms_split_kernel"], 2) for i in infos]},
+                         "split_row_kernel": [round(i["ms_split_kernel"], 2) for i in infos],
+                         "direct_plan_kernel": [round(i["ms_direct_plan_kernel"], 2) for i in infos]},
             "result_check": chk,
         })
         status = 0
@@ -491,6 +657,11 @@ def main():
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             if out["slab_parity"]["status"] != "ok":
                 status = 3
+        if args.ingest and not args.stream_output:
+            note("ingest: device COO -> CSC/CSR of the full operands, host parse")
+            out["ingest"] = ingest_report(ctx, n, csr, csc, np_dtype, device, args, ingest, bool(args.cpu_baseline))
+            note(f"ingest: device {out['ingest']['device_coo_to_compressed']['ms']:.1f} ms, host parse "
+                 f"{out['ingest']['host_parse'][0]['M_entries_per_s']:.1f} M entries/s")
         # the reference's own closed-form prediction for this input (SimOuterSPACE.cpp:176-238), beside the
         # measurement: simulated cycles of a 256-PE OuterSPACE at 85 B/cycle of DRAM, and the DRAM bytes it prices
         from outerspace_amd import cost_model
@@ -507,7 +678,7 @@ def main():
         if t:
             roof["traffic"], roof["traffic_source"] = t
         default_workload = (args.workload == "rmat" and args.rmat == "mild" and args.scale == 22 and not args.stream_output
-                            and args.partial_capacity == 0)
+                            and args.partial_capacity == 0 and a_mtx is None)
         if args.extras and default_workload and status == 0:
             # driver-observed numbers for the workloads the headline does not cover (3 steps each, same checks)
             del csr, csc, step, ptrs
@@ -515,13 +686,14 @@ def main():
             torch.cuda.empty_cache()
             extras = {}
             for name, make, stream in (
+                    ("rmat22_g500_streamed", lambda: rmat_device(22, 16, gen.RMAT_PRESETS["g500"], args.seed, device, tdtype), True),
                     ("rmat20_g500_streamed", lambda: rmat_device(20, 16, gen.RMAT_PRESETS["g500"], args.seed, device, tdtype), True),
                     ("rmat22_uniform", lambda: rmat_device(22, 16, gen.RMAT_PRESETS["uniform"], args.seed, device, tdtype), False),
-                    ("webgoogle_shape", lambda: webgoogle_device(args.seed, device, tdtype), False)):
+                    ("webgoogle_shape", lambda: webgoogle_operands(args.seed, device, tdtype), False)):
                 note(f"extra workload {name}")
                 n2, csr2, csc2 = make()
                 extras[name] = extra_workload(ctx, name, n2, csr2, csc2, args, np_dtype, tdtype, device, E, stream,
-                                              steps=5 if name == "webgoogle_shape" else 3)
+                                              steps={"webgoogle_shape": 5, "rmat22_g500_streamed": 2}.get(name, 3))
                 del csr2, csc2
                 ctx.trim()
                 torch.cuda.empty_cache()

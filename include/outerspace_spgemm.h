@@ -105,6 +105,10 @@ typedef struct osp_result_info {
     uint64_t split_partials;    /* partial products those launches moved (lower bound: heavy_partials minus the
                                    capacity of the stretch-split jobs) */
     uint64_t dense_segments;    /* over-long segments of hub rows reduced by dense accumulation (no sort) */
+    uint64_t direct_rows;       /* long rows the multiply phase wrote straight into their column ranges (no split pass) */
+    uint64_t direct_partials;   /* partial products in those rows */
+    float ms_direct_plan_kernel;/* direct_plan_kernel launches alone (range tables and cells of those rows) */
+    uint32_t direct_plan_launches;
     uint32_t rank_atomic;       /* 1: stable radix ranks from the return order of LDS atomics, 0: from ballot matching   */
     uint32_t dense_atomic;      /* 1: dense segments summed by LDS floating-point atomics, 0: by ballot ranks and rounds */
                                 /* (both variants are exact; a context picks them by a self-test)         */
@@ -228,6 +232,20 @@ int osp_result_partials(osp_result_t r, const int64_t **rowptr, const void **rec
 int osp_merge_record_parts(osp_context_t ctx, osp_dtype_t dtype, uint64_t M, uint64_t N, int nparts,
                            const int64_t *const *rowptrs, const void *const *records, osp_memspace_t space,
                            const osp_config_t *cfg, osp_result_t *result);
+
+/* ---- between the layers of a sparse MLP --------------------------------- */
+/*
+ * out = relu(C + bias) with the zeros dropped, as a new CSR result on the same context: what NN_models/models.py:17-31
+ * does to a layer's product before it feeds the next layer (x = relu(fc(x)); fc adds its bias to EVERY element, so a
+ * biased row is dense before the ReLU: out[i,j] = relu(C[i,j] + bias[j]) for all j, an absent C[i,j] counting as 0).
+ * bias: N values of C's dtype (host or device) or NULL (then only stored entries are touched); relu != 0 applies
+ * max(., 0).  Row pointers are exact, columns ascend.  `in` stays valid.  No reference kernel: the reference's layers
+ * are dense torch ops and its hand-off is a .mtx file per activation (get_mtx_files.py:76-96).
+ */
+int osp_csr_bias_relu(osp_result_t in, const void *bias, osp_memspace_t bias_space, int relu, osp_result_t *out);
+/* The row index of every entry of a CSR result (nnz_c values, DEVICE memory of the caller): with the result's colidx /
+ * vals arrays that is the COO form osp_spgemm_coo takes, so an activation feeds the next product without leaving the GPU. */
+int osp_result_coo_rows(osp_result_t r, uint32_t *rows_device);
 
 /* ---- results --------------------------------------------------------------------------- */
 int osp_result_info(osp_result_t r, osp_result_info_t *info);

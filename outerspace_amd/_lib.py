@@ -44,7 +44,9 @@ class ResultInfo(C.Structure):
                 ("ms_multiply_kernel", C.c_float), ("ms_merge_kernel", C.c_float), ("ms_ingest", C.c_float),
                 ("multiply_launches", C.c_uint32), ("merge_launches", C.c_uint32), ("dtype", C.c_int),
                 ("ms_split_kernel", C.c_float), ("split_launches", C.c_uint32), ("split_partials", C.c_uint64),
-                ("dense_segments", C.c_uint64), ("rank_atomic", C.c_uint32), ("dense_atomic", C.c_uint32)]
+                ("dense_segments", C.c_uint64), ("direct_rows", C.c_uint64), ("direct_partials", C.c_uint64),
+                ("ms_direct_plan_kernel", C.c_float), ("direct_plan_launches", C.c_uint32),
+                ("rank_atomic", C.c_uint32), ("dense_atomic", C.c_uint32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -68,7 +70,7 @@ EXPORTS = [
     "osp_spgemm_partials", "osp_result_partials", "osp_merge_record_parts",
     "osp_merge_csr_parts", "osp_result_info", "osp_result_copy_csr", "osp_result_device_ptrs",
     "osp_result_destroy", "osp_mtx_read", "osp_host_free", "osp_coo_to_compressed_f32",
-    "osp_coo_to_compressed_f64", "osp_spgemm_mtx", "osp_result_write_mtx",
+    "osp_coo_to_compressed_f64", "osp_spgemm_mtx", "osp_result_write_mtx", "osp_csr_bias_relu", "osp_result_coo_rows",
 ]
 
 _lib = None
@@ -127,6 +129,8 @@ def lib():
         getattr(L, f"osp_coo_to_compressed_{sfx}").argtypes = [i32, u64, u64, vp, vp, vp, vp, vp, vp]
     L.osp_spgemm_mtx.argtypes = [vp, i32, C.c_char_p, C.c_char_p, i32, C.POINTER(Config), C.POINTER(vp)]
     L.osp_result_write_mtx.argtypes = [vp, C.c_char_p]
+    L.osp_csr_bias_relu.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+    L.osp_result_coo_rows.argtypes = [vp, vp]
     _lib = L
     return L
 

@@ -21,6 +21,7 @@
 #include "osp_kernels.h"
 #include "osp_split.h"
 #include "osp_sort.h"
+#include "osp_epilogue.h"
 
 namespace osp {
 
@@ -245,7 +246,7 @@ struct Result {
 
 struct PhaseTimer {
     hipStream_t s;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[7];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[8];
     explicit PhaseTimer(hipStream_t st) : s(st) {}
     ~PhaseTimer() {
         for (auto &v : ev) for (auto &p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -276,7 +277,7 @@ struct EventPair {
     EventPair &operator=(const EventPair &) = delete;
     float ms() const { float t = 0; (void)hipEventElapsedTime(&t, a, b); return t; }
 };
-enum { PH_SYM = 0, PH_MUL = 1, PH_MERGE = 2, PH_COMPACT = 3, PH_MUL_K = 4, PH_MERGE_K = 5, PH_SPLIT_K = 6 };
+enum { PH_SYM = 0, PH_MUL = 1, PH_MERGE = 2, PH_COMPACT = 3, PH_MUL_K = 4, PH_MERGE_K = 5, PH_SPLIT_K = 6, PH_PLAN_K = 7 };
 
 // debugging aid: OSP_SYNC=1 waits for the stream at the marked points of a product and names them on stderr, so
 // that an asynchronous GPU fault is pinned to the step that caused it (the last name printed COMPLETED)
@@ -452,8 +453,10 @@ template <class T> static T d2h(const T *dptr, hipStream_t s) {
 template <class T> struct Producer {
     virtual ~Producer() {}
     // enqueue kernels that fill stage[0 .. row_off[r1]-row_off[r0]) for rows [r0,r1)
+    // (cells / qstage: the plan and the second buffer of the panel's direct rows, osp_kernels.h store_direct; null
+    // when the panel has none)
     virtual void produce(uint64_t r0, uint64_t r1, bool whole, uint64_t base, uint64_t count,
-                         Part<T> *stage, PhaseTimer &tm) = 0;
+                         Part<T> *stage, PhaseTimer &tm, const uint32_t *cells = nullptr, Part<T> *qstage = nullptr) = 0;
 };
 
 // ---- rows of partial products -> merged rows -------------------------------------------------------
@@ -502,83 +505,173 @@ static TilePlan plan_tiles(Context *ctx, Scratch &sc, const uint64_t *row_off, u
     return pl;
 }
 
-// One panel: tiles of rows, long rows split into column-range segments whose tiles take the long row's
-// place in ONE offset chain, so every merged entry is written once, straight to the final CSR.
+// What the planner of direct rows reads -- the chunk table of the symbolic phase: the chunks (non-zeros of A) in (row, k)
+// order with their staging offsets and B rows -- and the chunk offsets it replaces by descriptors (osp_kernels.h,
+// store_direct).  direct_max: longest row (partial products) that is planned as a direct row.
+struct DirectSrc {
+    const uint32_t *rowfirst; const uint64_t *off; const uint32_t *bs; const uint32_t *perm; const uint32_t *b_colidx;
+    uint64_t *chunk_off;
+    uint64_t direct_max;
+};
+
+// What is decided about a panel BEFORE its partial products exist (plan_panel) and used after the multiply (merge_panel).
+template <class T> struct PanelPlan {
+    Scratch sc;           // owns every array below; released when the panel is done
+    TilePlan p0;          // level-0 tiles and the list of long rows
+    uint32_t max_rows = 0;
+    // ---- long rows ----
+    uint64_t *hoff = nullptr, *hscan_tmp = nullptr, *blkbase = nullptr, *hbase = nullptr, *vbase = nullptr, *cellbase = nullptr;
+    uint8_t *hbits = nullptr, *hmode = nullptr;
+    uint32_t *nstretch = nullptr;
+    uint64_t nh = 0, nblocks = 0, nvirt = 0, ncell = 0;
+    uint64_t mode_rows[3] = {0, 0, 0}, mode_partials[3] = {0, 0, 0};   // per kMode*: how many long rows, how many partial products
+    uint32_t *ghist = nullptr, *ghist_tmp = nullptr;
+    Part<T> *qstage = nullptr;        // the second buffer: long rows by column range
+    uint64_t *vrow_off = nullptr;     // its segments ("virtual rows"): offsets, first-of-row flags, column bounds
+    uint8_t *vfirst = nullptr;
+    uint32_t *vcol0 = nullptr, *vcol1 = nullptr;
+    uint32_t *cells = nullptr;        // direct rows: range tables and (chunk, range) cells
+    explicit PanelPlan(Context *c) : sc(c) {}
+};
+
+// totals[mode] += rows, totals[3 + mode] += partial products, per mode of the long rows
+__global__ void mode_totals_kernel(const uint32_t *rows, uint32_t nlong, const uint64_t *row_off, const uint8_t *hmode,
+                                   unsigned long long *totals) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool on = h < nlong;
+    const uint64_t U = on ? row_off[rows[h] + 1] - row_off[rows[h]] : 0ull;
+    const uint8_t m = on ? hmode[h] : (uint8_t)255;
+    for (uint8_t mode = 0; mode < 3; mode++) {
+        const uint64_t part = wave_reduce_sum<uint64_t>(m == mode ? U : 0ull);
+        const uint64_t cnt = __popcll(__ballot(m == mode));
+        if (lane_id() == 0 && cnt) { atomicAdd(&totals[mode], (unsigned long long)cnt); atomicAdd(&totals[3 + mode], (unsigned long long)part); }
+    }
+}
+
+// Before the multiply: level-0 tiles, the long rows and how each of them will reach the tile kernel, the second buffer
+// and its segment tables -- and, for direct rows, the plan the multiply writes them by.
 template <class T>
-static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO<T> &io, int colbits) {
+static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &pl, const uint64_t *row_off, uint64_t r0, uint64_t r1,
+                       uint64_t base, int colbits, const DirectSrc *ds) {
     hipStream_t s = ctx->stream;
-    Scratch sc(ctx);
+    Scratch &sc = pl.sc;
     constexpr uint32_t kCap = (uint32_t)TileCap<T>::value;
-    const uint32_t max_rows = (uint32_t)std::min<uint64_t>(kTileMaxRows, colbits >= 32 ? 1ull : (1ull << (32 - colbits)));
+    pl.max_rows = (uint32_t)std::min<uint64_t>(kTileMaxRows, colbits >= 32 ? 1ull : (1ull << (32 - colbits)));
+    pl.p0 = plan_tiles(ctx, sc, row_off, r0, r1, base, kCap, pl.max_rows, nullptr);
+    res->info.light_tiles += pl.p0.ntiles - pl.p0.nlong;
+    if (!pl.p0.nlong) return;
+    const uint32_t nlong = pl.p0.nlong;
+    pl.hoff = sc.get<uint64_t>((uint64_t)nlong + 1);
+    pl.hscan_tmp = sc.get<uint64_t>(scan_scratch_entries(nlong));
+    device_exclusive_scan<HeavyLen, uint64_t>(HeavyLen{pl.p0.long_rows, row_off}, nlong, pl.hoff, pl.hscan_tmp, s);
+    pl.hbits = sc.get<uint8_t>(nlong);
+    pl.hmode = sc.get<uint8_t>(nlong);
+    pl.nstretch = sc.get<uint32_t>(nlong);
+    uint32_t *nseg = sc.get<uint32_t>(nlong);
+    uint64_t *nhist = sc.get<uint64_t>(nlong), *ncellh = sc.get<uint64_t>(nlong);
+    pl.blkbase = sc.get<uint64_t>((uint64_t)nlong + 1); pl.hbase = sc.get<uint64_t>((uint64_t)nlong + 1);
+    pl.vbase = sc.get<uint64_t>((uint64_t)nlong + 1); pl.cellbase = sc.get<uint64_t>((uint64_t)nlong + 1);
+    unsigned long long *totals = (unsigned long long *)sc.get<uint64_t>(6);
+    OSP_HIP(hipMemsetAsync(totals, 0, 6 * sizeof(uint64_t), s));
+    // debugging aid: OSP_SPLIT_ROW_MAX moves the boundary between the two split kernels (tests run both on small inputs)
+    const uint64_t row_max = getenv("OSP_SPLIT_ROW_MAX") ? strtoull(getenv("OSP_SPLIT_ROW_MAX"), nullptr, 10) : kSplitRowMax;
+    // no more ranges than make a range as narrow as the dense accumulators take (osp_split.h, kDenseBits): beyond that
+    // a finer split only shortens the runs the scatter writes -- whatever a range of <= 1024 columns holds is summed
+    // without a sort.  (Only bites when N < 2^22: 4096 ranges of 1024 columns.)
+    const int bits_cap = getenv("OSP_SPLIT_BITS_CAP") ? atoi(getenv("OSP_SPLIT_BITS_CAP")) : std::max(colbits - kDenseBits, kSplitRowBits);
+    split_params_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(pl.p0.long_rows, nlong, row_off, colbits, row_max, bits_cap, ds ? ds->rowfirst : nullptr,
+                                                             ds ? ds->direct_max : 0ull, kCap, pl.hbits, pl.hmode, pl.nstretch, nseg, nhist, ncellh);
+    mode_totals_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(pl.p0.long_rows, nlong, row_off, pl.hmode, totals);
+    device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{pl.nstretch}, nlong, pl.blkbase, pl.hscan_tmp, s);
+    device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nseg}, nlong, pl.vbase, pl.hscan_tmp, s);
+    device_exclusive_scan<LoadU64, uint64_t>(LoadU64{nhist}, nlong, pl.hbase, pl.hscan_tmp, s);
+    if (ds) device_exclusive_scan<LoadU64, uint64_t>(LoadU64{ncellh}, nlong, pl.cellbase, pl.hscan_tmp, s);
+    uint64_t ndcell = 0, tot[6] = {0, 0, 0, 0, 0, 0};
+    {
+        Gather g(s);
+        g.add(&pl.nh, (const uint64_t *)pl.hoff + nlong); g.add(&pl.nblocks, (const uint64_t *)pl.blkbase + nlong);
+        g.add(&pl.nvirt, (const uint64_t *)pl.vbase + nlong); g.add(&pl.ncell, (const uint64_t *)pl.hbase + nlong);
+        if (ds) g.add(&ndcell, (const uint64_t *)pl.cellbase + nlong);
+        for (int i = 0; i < 6; i++) g.add(&tot[i], (const uint64_t *)totals + i);
+        g.wait();
+    }
+    for (int m = 0; m < 3; m++) { pl.mode_rows[m] = tot[m]; pl.mode_partials[m] = tot[3 + m]; }
+    if (pl.nh >= 0xffffffffull) throw Error(OSP_ERR_CAPACITY, "long rows of one panel exceed 2^32 partial products");
+    res->info.heavy_rows += nlong;
+    res->info.heavy_partials += pl.nh;
+    res->info.direct_rows += pl.mode_rows[kModeDirect];
+    res->info.direct_partials += pl.mode_partials[kModeDirect];
+    if (pl.ncell >= 0xffffffffull || pl.nblocks >= 0x7fffffffull || pl.nvirt >= 0xffffffffull || ndcell >= 0xffffffffull)
+        throw Error(OSP_ERR_CAPACITY, "split histogram too large");
+    if (getenv("OSP_VERBOSE"))
+        fprintf(stderr, "[osp]   panel rows [%llu,%llu): %u tiles, %u long rows with %llu partial products -> %llu segments; direct: %llu rows, %llu "
+                        "partial products, %llu cells\n",
+                (unsigned long long)r0, (unsigned long long)r1, pl.p0.ntiles, nlong, (unsigned long long)pl.nh, (unsigned long long)pl.nvirt,
+                (unsigned long long)pl.mode_rows[kModeDirect], (unsigned long long)pl.mode_partials[kModeDirect], (unsigned long long)ndcell);
+    pl.ghist = sc.get<uint32_t>(pl.ncell + 1);
+    pl.ghist_tmp = sc.get<uint32_t>(scan_scratch_entries(pl.ncell + 1));
+    pl.qstage = sc.get<Part<T>>(pl.nh);
+    pl.vrow_off = sc.get<uint64_t>(pl.nvirt + 1);
+    pl.vfirst = sc.get<uint8_t>(pl.nvirt + 1);
+    pl.vcol0 = sc.get<uint32_t>(pl.nvirt + 1);
+    pl.vcol1 = sc.get<uint32_t>(pl.nvirt + 1);
+    if (pl.mode_rows[kModeDirect]) {
+        pl.cells = sc.get<uint32_t>(ndcell);
+        tm.begin(PH_PLAN_K);
+        direct_plan_kernel<<<nlong, kDirectThreads, 0, s>>>(pl.p0.long_rows, nlong, pl.hmode, pl.hbits, nseg, pl.vbase, pl.hoff, pl.cellbase, row_off,
+                                                           colbits, kCap, ds->rowfirst, ds->off, ds->bs, ds->perm, ds->b_colidx, pl.vrow_off,
+                                                           pl.vcol0, pl.vcol1, pl.cells, ds->chunk_off);
+        tm.end(PH_PLAN_K);
+        res->info.direct_plan_launches++;
+        dbg_sync(s, "plan of the direct rows");
+    }
+}
+
+// One panel after the multiply: long rows that are not direct are split into column-range segments; the tiles of all
+// segments take their long row's place in ONE offset chain, so every merged entry is written once, straight to the
+// final CSR.
+template <class T>
+static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO<T> &io, int colbits, PanelPlan<T> &pl) {
+    hipStream_t s = ctx->stream;
+    Scratch &sc = pl.sc;
+    constexpr uint32_t kCap = (uint32_t)TileCap<T>::value;
+    const uint32_t max_rows = pl.max_rows;
 #ifdef OSP_CHECK_DESC
     crumbs_init();
 #endif
-    const uint64_t r0 = io.r0, r1 = io.r1, base = io.base;
-    const TilePlan p0 = plan_tiles(ctx, sc, io.row_off, r0, r1, base, kCap, max_rows, nullptr);
-    res->info.light_tiles += p0.ntiles - p0.nlong;
+    const uint64_t r1 = io.r1, base = io.base;
+    const TilePlan &p0 = pl.p0;
 
     MergeLevels<T> lv{};
     lv.stage[0] = io.stage; lv.row_off[0] = io.row_off; lv.base[0] = base; lv.c_rowptr[0] = io.c_rowptr; lv.heavy_nnz[0] = nullptr;
     uint32_t ntot = p0.ntiles;
     TileDesc *desc = nullptr;
-    // level-1 state (split long rows)
+    // level-1 state (long rows by column range)
     TilePlan p1;
-    uint64_t *vbase = nullptr;
+    uint64_t *vbase = pl.vbase;
     int64_t *vptr = nullptr;
     uint64_t *seg_src = nullptr;   // too-long segments: where their reduced entries sit in the second buffer
     uint32_t *seg_nnz = nullptr;
-    Part<T> *qstage = nullptr;
+    Part<T> *qstage = pl.qstage;
     if (p0.nlong) {
         const uint32_t nlong = p0.nlong;
-        uint64_t *hoff = sc.get<uint64_t>((uint64_t)nlong + 1);
-        uint64_t *hscan_tmp = sc.get<uint64_t>(scan_scratch_entries(nlong));
-        device_exclusive_scan<HeavyLen, uint64_t>(HeavyLen{p0.long_rows, io.row_off}, nlong, hoff, hscan_tmp, s);
-        // (read back below, together with the split's sizes: one wait instead of four)
-        // ---- one stable split by column range into the second buffer ----
-        uint8_t *hbits = sc.get<uint8_t>(nlong);
-        uint32_t *nstretch = sc.get<uint32_t>(nlong), *nseg = sc.get<uint32_t>(nlong);
-        uint64_t *nhist = sc.get<uint64_t>(nlong);
-        uint64_t *blkbase = sc.get<uint64_t>((uint64_t)nlong + 1), *hbase = sc.get<uint64_t>((uint64_t)nlong + 1);
-        vbase = sc.get<uint64_t>((uint64_t)nlong + 1);
-        // debugging aid: OSP_SPLIT_ROW_MAX moves the boundary between the two split kernels (tests run both on small inputs)
-        const uint64_t row_max = getenv("OSP_SPLIT_ROW_MAX") ? strtoull(getenv("OSP_SPLIT_ROW_MAX"), nullptr, 10) : kSplitRowMax;
-        // no more ranges than make a range as narrow as the dense accumulators take (osp_split.h, kDenseBits): beyond that
-        // a finer split only shortens the runs the scatter writes -- whatever a range of <= 1024 columns holds is summed
-        // without a sort.  (Only bites when N < 2^22: 4096 ranges of 1024 columns.)
-        const int bits_cap = getenv("OSP_SPLIT_BITS_CAP") ? atoi(getenv("OSP_SPLIT_BITS_CAP")) : std::max(colbits - kDenseBits, kSplitRowBits);
-        split_params_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(p0.long_rows, nlong, io.row_off, colbits, row_max, bits_cap, hbits, nstretch, nseg,
-                                                                 nhist);
-        device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nstretch}, nlong, blkbase, hscan_tmp, s);
-        device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nseg}, nlong, vbase, hscan_tmp, s);
-        device_exclusive_scan<LoadU64, uint64_t>(LoadU64{nhist}, nlong, hbase, hscan_tmp, s);
-        uint64_t nh = 0, nblocks = 0, nvirt = 0, ncell = 0;
-        {
-            Gather g(s);
-            g.add(&nh, (const uint64_t *)hoff + nlong); g.add(&nblocks, (const uint64_t *)blkbase + nlong);
-            g.add(&nvirt, (const uint64_t *)vbase + nlong); g.add(&ncell, (const uint64_t *)hbase + nlong);
-            g.wait();
-        }
-        if (nh >= 0xffffffffull) throw Error(OSP_ERR_CAPACITY, "long rows of one panel exceed 2^32 partial products");
-        res->info.heavy_rows += nlong;
-        res->info.heavy_partials += nh;
-        if (ncell >= 0xffffffffull || nblocks >= 0x7fffffffull || nvirt >= 0xffffffffull)
-            throw Error(OSP_ERR_CAPACITY, "split histogram too large");
-        if (getenv("OSP_VERBOSE"))
-            fprintf(stderr, "[osp]   panel rows [%llu,%llu): %u tiles, %u long rows with %llu partial products -> %llu segments\n",
-                    (unsigned long long)r0, (unsigned long long)r1, p0.ntiles, nlong, (unsigned long long)nh, (unsigned long long)nvirt);
-        uint32_t *ghist = sc.get<uint32_t>(ncell + 1);
-        uint32_t *ghist_tmp = sc.get<uint32_t>(scan_scratch_entries(ncell + 1));
-        qstage = sc.get<Part<T>>(nh);
-        uint64_t *vrow_off = sc.get<uint64_t>(nvirt + 1);
-        uint8_t *vfirst = sc.get<uint8_t>(nvirt + 1);
+        uint64_t *hoff = pl.hoff, *hscan_tmp = pl.hscan_tmp, *blkbase = pl.blkbase, *hbase = pl.hbase;
+        uint8_t *hbits = pl.hbits;
+        uint32_t *nstretch = pl.nstretch, *ghist = pl.ghist, *ghist_tmp = pl.ghist_tmp;
+        const uint64_t nh = pl.nh, nblocks = pl.nblocks, nvirt = pl.nvirt, ncell = pl.ncell;
+        uint64_t *vrow_off = pl.vrow_off;
+        uint8_t *vfirst = pl.vfirst;
+        // ---- rows that are not direct: one stable split by column range into the second buffer ----
         // rows up to kSplitRowMax: one workgroup each (histogram, scan and scatter in one kernel)
-        tm.begin(PH_SPLIT_K);
-        OSP_WITH_RA(ctx, split_row_kernel<T, RA><<<nlong, kSplitRowThreads, 0, s>>>(p0.long_rows, nlong, hbits, nstretch, vbase, hoff, io.row_off,
-                                                                                 base, colbits, io.stage, qstage, vrow_off));
-        tm.end(PH_SPLIT_K);
-        res->info.split_launches++;
-        res->info.split_partials += nh - std::min<uint64_t>(nh, nblocks * (uint64_t)kSplitJob);
-        dbg_sync(s, "split: one-workgroup rows");
+        if (pl.mode_rows[kModeSplitRow]) {
+            tm.begin(PH_SPLIT_K);
+            OSP_WITH_RA(ctx, split_row_kernel<T, RA><<<nlong, kSplitRowThreads, 0, s>>>(p0.long_rows, nlong, hbits, pl.hmode, vbase, hoff, io.row_off,
+                                                                                     base, colbits, io.stage, qstage, vrow_off));
+            tm.end(PH_SPLIT_K);
+            res->info.split_launches++;
+            res->info.split_partials += pl.mode_partials[kModeSplitRow];
+            dbg_sync(s, "split: one-workgroup rows");
+        }
         if (nblocks) {  // longer rows: one workgroup per 4096-entry stretch, offsets from a device-wide scan
             split_count_kernel<<<(unsigned)nblocks, kSplitThreads, 0, s>>>(p0.long_rows, nlong, blkbase, hbase, hbits, nstretch, io.row_off,
                                                                          base, colbits, (const char *)io.stage, (uint32_t)sizeof(Part<T>), ghist);
@@ -587,7 +680,8 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
                                  p0.long_rows, nlong, blkbase, hbase, hbits, nstretch, io.row_off, base, colbits, io.stage, ghist, hoff, qstage));
         }
         dbg_sync(s, "split: stretch rows");
-        split_vrows_kernel<<<grid_for(nvirt + 1, 256), 256, 0, s>>>(nlong, vbase, hbase, nstretch, ghist, hoff, nvirt, nh, vrow_off, vfirst);
+        split_vrows_kernel<<<grid_for(nvirt + 1, 256), 256, 0, s>>>(nlong, vbase, hbase, nstretch, hbits, pl.hmode, colbits, ghist, hoff, nvirt, nh,
+                                                                   vrow_off, vfirst, pl.vcol0, pl.vcol1);
         OSP_HIP(hipGetLastError());
         dbg_sync(s, "split: segment offsets");
         // ---- tiles over the segments; a tile never spans two long rows ----
@@ -608,18 +702,18 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
             uint32_t *hscan = sc.get<uint32_t>((uint64_t)nseg_long + 1);
             uint64_t *sscan_tmp = sc.get<uint64_t>(scan_scratch_entries(nseg_long));  // NOT hscan_tmp: that one is sized for nlong
             {
-                const SegDenseFlag df{p1.long_rows, vbase, hbits, nlong, colbits, getenv("OSP_DENSE_SEG") ? atoi(getenv("OSP_DENSE_SEG")) : 1};
+                const SegDenseFlag df{p1.long_rows, pl.vcol0, pl.vcol1, getenv("OSP_DENSE_SEG") ? atoi(getenv("OSP_DENSE_SEG")) : 1};
                 device_exclusive_scan<SegDenseFlag, uint32_t>(df, nseg_long, hscan, (uint32_t *)sscan_tmp, s);
                 const uint32_t ndense = d2h(hscan + nseg_long, s);
                 if (ndense) {
                     uint32_t *dense_list = sc.get<uint32_t>(ndense), *others = sc.get<uint32_t>(nseg_long - ndense);
                     seg_split_list_kernel<SegDenseFlag><<<grid_for(nseg_long, 256), 256, 0, s>>>(df, hscan, nseg_long, dense_list, others);
                     if (ctx->dense_atomic[sizeof(T) == 8])
-                        dense_segment_kernel<T, true><<<grid_for(ndense, kDenseWaves), kDenseWaves * kWave, 0, s>>>(dense_list, ndense, vrow_off, vbase, hbits, nlong, colbits, qstage,
-                                                                              seg_nnz);
+                        dense_segment_kernel<T, true><<<grid_for(ndense, kDenseWaves), kDenseWaves * kWave, 0, s>>>(dense_list, ndense, vrow_off, pl.vcol0, pl.vcol1,
+                                                                              qstage, seg_nnz);
                     else
-                        dense_segment_kernel<T, false><<<grid_for(ndense, kDenseWaves), kDenseWaves * kWave, 0, s>>>(dense_list, ndense, vrow_off, vbase, hbits, nlong, colbits, qstage,
-                                                                              seg_nnz);
+                        dense_segment_kernel<T, false><<<grid_for(ndense, kDenseWaves), kDenseWaves * kWave, 0, s>>>(dense_list, ndense, vrow_off, pl.vcol0, pl.vcol1,
+                                                                              qstage, seg_nnz);
                     res->info.dense_segments += ndense;
                     rest_list = others;
                     nrest = nseg_long - ndense;
@@ -644,7 +738,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
             res->info.sorted_segments += nhuge;
             if (nmid) {
                 TileDesc *bdesc = sc.get<TileDesc>(nmid);
-                seg_tile_desc_kernel<<<grid_for(nmid, 256), 256, 0, s>>>(mid_list, nmid, vrow_off, vbase, hbits, nlong, colbits, bdesc);
+                seg_tile_desc_kernel<<<grid_for(nmid, 256), 256, 0, s>>>(mid_list, nmid, vrow_off, pl.vcol0, pl.vcol1, bdesc);
                 uint32_t *bticket = sc.get<uint32_t>(1);
                 OSP_HIP(hipMemsetAsync(bticket, 0, sizeof(uint32_t), s));
                 const uint32_t bgrid = ctx->cus * (uint32_t)merge_wgs_per_cu<T, kBigTileThreads, kBigTileCap>();
@@ -690,14 +784,14 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         ntot = p0.ntiles + d2h(extra + nlong, s);
         desc = sc.get<TileDesc>(ntot);
         tile_desc_kernel<(int)kCap><<<grid_for(p0.ntiles, 256), 256, 0, s>>>(p0.tile_rows, p0.ntiles, r1, io.row_off, base, 0u, j0, extra,
-                                                                           nlong, tb, colbits, hbits, vbase, desc);
+                                                                           nlong, tb, pl.vcol0, pl.vcol1, desc);
         tile_desc_kernel<(int)kCap><<<grid_for(p1.ntiles, 256), 256, 0, s>>>(p1.tile_rows, p1.ntiles, nvirt, vrow_off, 0, 1u, j0, extra,
-                                                                           nlong, tb, colbits, hbits, vbase, desc);
+                                                                           nlong, tb, pl.vcol0, pl.vcol1, desc);
         dbg_sync(s, "tile chain");
     } else {
         desc = sc.get<TileDesc>(ntot);
         tile_desc_kernel<(int)kCap><<<grid_for(p0.ntiles, 256), 256, 0, s>>>(p0.tile_rows, p0.ntiles, r1, io.row_off, base, 0u, nullptr,
-                                                                           nullptr, 0u, nullptr, colbits, nullptr, nullptr, desc);
+                                                                           nullptr, 0u, nullptr, nullptr, nullptr, desc);
     }
     uint64_t *tile_status = sc.get<uint64_t>(ntot);
     uint32_t *ticket = sc.get<uint32_t>(1);
@@ -741,7 +835,8 @@ template <class T>
 static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_t M_all, uint64_t N,
                            const uint64_t *d_row_off,
                            uint64_t P, uint64_t cap_cfg, PhaseTimer &tm, uint64_t r_lo = 0, uint64_t r_hi = ~0ull,
-                           uint64_t off_lo = 0, const PanelSink *sink = nullptr, const ChunkTable<T> *ct = nullptr) {
+                           uint64_t off_lo = 0, const PanelSink *sink = nullptr, const ChunkTable<T> *ct = nullptr,
+                           const DirectSrc *ds = nullptr) {
     // output rows [r_lo, r_hi) only (row-sharded multi-GPU mode); P = their partial products, off_lo = row_off[r_lo]
     if (r_hi == ~0ull) r_hi = M_all;
     const uint64_t M = r_hi - r_lo;
@@ -850,14 +945,18 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
             const uint64_t r0 = bounds[p], r1 = bounds[p + 1];
             const uint64_t base = (npanels == 1) ? off_lo : h_off[r0];
             const uint64_t count = (npanels == 1) ? P : h_off[r1] - base;
+            PanelPlan<T> plan(ctx);
+            tm.begin(PH_MERGE);
+            plan_panel<T>(ctx, res, tm, plan, d_row_off, r0, r1, base, colbits, ds);
+            tm.end(PH_MERGE);
             tm.begin(PH_MUL);
-            if (count) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm);
+            if (count) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm, plan.cells, plan.qstage);
             tm.end(PH_MUL);
             tm.begin(PH_MERGE);
             OSP_HIP(hipMemsetAsync(cells, 0, 2 * sizeof(uint64_t), s));
             MergeIO<T> io{stage, d_row_off, r0, r1, base, prow - r0, c_col, c_val, cells, cells + 1};
             if (ct) io.ct = *ct;
-            merge_panel<T>(ctx, res, tm, io, colbits);
+            merge_panel<T>(ctx, res, tm, io, colbits, plan);
             tm.end(PH_MERGE);
             const uint64_t nnz_p = d2h(cells + 1, s);  // synchronises: the panel is complete
             nnz_total += nnz_p;
@@ -875,14 +974,18 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         const uint64_t base = (npanels == 1) ? off_lo : h_off[r0];
         const uint64_t count = (npanels == 1) ? P : h_off[r1] - base;
         // ---- multiply (or scatter of CSR parts) ----
+        PanelPlan<T> plan(ctx);
+        tm.begin(PH_MERGE);
+        plan_panel<T>(ctx, res, tm, plan, d_row_off, r0, r1, base, colbits, ds);
+        tm.end(PH_MERGE);
         tm.begin(PH_MUL);
-        if (count) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm);
+        if (count) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm, plan.cells, plan.qstage);
         tm.end(PH_MUL);
         // ---- merge ----
         tm.begin(PH_MERGE);
         MergeIO<T> io{stage, d_row_off, r0, r1, base, res->rowptr - r_lo, c_col, c_val, out_nnz + p, out_nnz + p + 1};
         if (ct) io.ct = *ct;
-        merge_panel<T>(ctx, res, tm, io, colbits);
+        merge_panel<T>(ctx, res, tm, io, colbits, plan);
         tm.end(PH_MERGE);
     }
     const uint64_t nnz_total = d2h(out_nnz + npanels, s);
@@ -911,11 +1014,11 @@ template <class T> struct OuterProducer : Producer<T> {
     const int64_t *a_colptr; const uint32_t *a_rowidx; const T *a_vals;
     const int64_t *b_rowptr; const uint32_t *b_colidx; const T *b_vals;
     uint64_t k0, k1; int64_t e0;
-    const uint64_t *chunk_off;
+    const uint64_t *chunk_off;   // (the planner of direct rows rewrites the entries of its chunks, panel by panel)
     int64_t *a_start; uint32_t *a_cnt; uint64_t *prod; uint64_t *prod_off; uint64_t *scan_tmp;
     bool nothing_staged = false;  // row-wise variant and no row is longer than a tile: the tile kernel does it all
     void produce(uint64_t r0, uint64_t r1, bool whole, uint64_t base, uint64_t count, Part<T> *stage,
-                 PhaseTimer &tm) override {
+                 PhaseTimer &tm, const uint32_t *cells, Part<T> *qstage) override {
         if (nothing_staged) return;
         hipStream_t s = ctx->stream;
         const uint64_t nk = k1 - k0;
@@ -926,7 +1029,7 @@ template <class T> struct OuterProducer : Producer<T> {
         dbg_sync(s, "panel columns + scan");
         tm.begin(PH_MUL_K);
         multiply_kernel<T><<<(unsigned)nblocks, kMulThreads, 0, s>>>(a_vals, b_colidx, b_vals, b_rowptr, chunk_off, e0,
-                                                                     a_start, a_cnt, prod_off, k0, nk, count, base, stage);
+                                                                     a_start, a_cnt, prod_off, k0, nk, count, base, stage, cells, qstage);
         tm.end(PH_MUL_K);
         dbg_sync(s, "multiply");
         res->info.multiply_launches++;
@@ -938,7 +1041,7 @@ template <class T> struct PartsProducer : Producer<T> {
     const int64_t *const *d_rowptrs; const uint32_t *const *d_colidxs; const T *const *d_valss;
     int nparts;
     const uint64_t *row_off;
-    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &) override {
+    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &, const uint32_t *, Part<T> *) override {
         const uint64_t nr = r1 - r0;
         parts_scatter_kernel<T><<<grid_for(nr * kWave, 256), 256, 0, ctx->stream>>>(d_rowptrs, d_colidxs, d_valss, nparts,
                                                                                     r0, r1, row_off, base, stage);
@@ -950,7 +1053,7 @@ template <class T> struct RecordPartsProducer : Producer<T> {
     const int64_t *const *d_rowptrs; const Part<T> *const *d_recs;
     int nparts;
     const uint64_t *row_off;
-    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &) override {
+    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &, const uint32_t *, Part<T> *) override {
         const uint64_t nr = r1 - r0;
         parts_scatter_rec_kernel<T><<<grid_for(nr * kWave, 256), 256, 0, ctx->stream>>>(d_rowptrs, d_recs, nparts, r0, r1, row_off, base, stage);
     }
@@ -1093,15 +1196,23 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     if (algo != OSP_ALGO_OUTER && algo != OSP_ALGO_ROWWISE) throw Error(OSP_ERR_ARG, "unknown algorithm");
     const bool rowwise = algo == OSP_ALGO_ROWWISE && nnz && (uint64_t)nnz_b < 0xffffffffull && nnz < 0xffffffffull && !partials_only;
     ChunkTable<T> ct{};
+    // Long rows that one workgroup could split are written straight into their column ranges by the multiply phase
+    // ("direct" rows, osp_split.h) when the operands allow 32-bit B offsets.  OSP_DIRECT=0 switches that off (every long
+    // row is then split after the multiply, as the parts-merging entry points do), OSP_DIRECT_MAX=<partial products>
+    // bounds the rows it applies to.
+    const bool direct = nnz && (uint64_t)nnz_b < 0xffffffffull && nnz < 0xffffffffull && !partials_only &&
+                        !(getenv("OSP_DIRECT") && atoi(getenv("OSP_DIRECT")) == 0);
+    const uint64_t direct_max = getenv("OSP_DIRECT_MAX") ? strtoull(getenv("OSP_DIRECT_MAX"), nullptr, 10) : kSplitRowMax;
+    DirectSrc dsrc{};
     uint32_t n_long_rows = 1;
     if (nnz == 0) {
         OSP_HIP(hipMemsetAsync(row_off, 0, (M + 1) * sizeof(uint64_t), s));
     } else {
         Scratch ss(ctx);
-        Scratch &keep = rowwise ? sc : ss;  // the chunk table outlives the symbolic phase
+        Scratch &keep = (rowwise || direct) ? sc : ss;  // the chunk table outlives the symbolic phase
         uint32_t *ka = ss.get<uint32_t>(nnz), *pa = ss.get<uint32_t>(nnz), *kb = ss.get<uint32_t>(nnz), *pb = ss.get<uint32_t>(nnz);
         uint32_t *rows_sorted = ss.get<uint32_t>(nnz), *perm = keep.get<uint32_t>(nnz), *w_sorted = ss.get<uint32_t>(nnz);
-        uint32_t *bs_sorted = rowwise ? keep.get<uint32_t>(nnz) : nullptr;
+        uint32_t *bs_sorted = (rowwise || direct) ? keep.get<uint32_t>(nnz) : nullptr;
         uint32_t *rowfirst = keep.get<uint32_t>(M + 1);
         uint32_t *hist = ss.get<uint32_t>(rs_hist_entries(nnz));
         uint32_t *hist_tmp = ss.get<uint32_t>(scan_scratch_entries(rs_hist_entries(nnz)));
@@ -1109,7 +1220,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         uint64_t *scan_tmp = ss.get<uint64_t>(scan_scratch_entries(std::max<uint64_t>(nnz, M + 1)));
         // (row, k) order of A's non-zeros; the last sort pass also looks up each chunk's length
         uint32_t *w = ss.get<uint32_t>(nnz);
-        uint32_t *bs = rowwise ? ss.get<uint32_t>(nnz) : nullptr;
+        uint32_t *bs = (rowwise || direct) ? ss.get<uint32_t>(nnz) : nullptr;
         sym_chunk_len_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(a_colptr, b_rowptr, k0, k1, e0, nnz, w, bs);
         device_sort_rows<SymEpilogue>(a_rowidx + e0, nnz, std::max(1, bits_for(M)), ka, pa, kb, pb, hist, hist_tmp,
                                       SymEpilogue{w, bs, rows_sorted, perm, w_sorted, bs_sorted}, s, ctx->rank_atomic);
@@ -1118,6 +1229,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         const uint64_t rw_cap = rowwise ? (uint64_t)TileCap<T>::value : 0ull;
         sym_scatter_offsets_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(perm, offs_sorted, rows_sorted, row_off, rw_cap, nnz, chunk_off);
         P = d2h(offs_sorted + nnz, s);
+        if (direct) dsrc = DirectSrc{rowfirst, offs_sorted, bs_sorted, perm, b_colidx, chunk_off, direct_max};
         if (rowwise) {
             ct = ChunkTable<T>{offs_sorted, bs_sorted, perm, rowfirst, a_vals + e0, b_colidx, b_vals, (uint32_t)rw_cap, 1u};
             uint32_t *flag_scan = ss.get<uint32_t>(M + 1);
@@ -1151,7 +1263,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         res->info.row_begin = 0;
         res->info.row_end = M;
         tm.begin(PH_MUL);
-        if (P) prod.produce(0, M, true, 0, P, (Part<T> *)res->vals, tm);
+        if (P) prod.produce(0, M, true, 0, P, (Part<T> *)res->vals, tm, nullptr, nullptr);
         tm.end(PH_MUL);
         OSP_HIP(hipEventRecord(ev.b, s));
         OSP_HIP(hipStreamSynchronize(s));
@@ -1164,7 +1276,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     // row-sharded: A holds this rank's rows only, so the staging offsets start at 0 at r_lo and P is the shard's count
     const uint64_t off_lo = 0, P_rows = P;
     merge_pipeline<T>(ctx, res, prod, M, N, row_off, P_rows, cfg.partial_capacity, tm, r_lo, r_hi, off_lo, sink,
-                      rowwise ? &ct : nullptr);
+                      rowwise ? &ct : nullptr, (direct && nnz) ? &dsrc : nullptr);
 
     OSP_HIP(hipEventRecord(ev.b, s));
     OSP_HIP(hipStreamSynchronize(s));
@@ -1181,6 +1293,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     res->info.ms_multiply_kernel = tm.total(PH_MUL_K);
     res->info.ms_merge_kernel = tm.total(PH_MERGE_K);
     res->info.ms_split_kernel = tm.total(PH_SPLIT_K);
+    res->info.ms_direct_plan_kernel = tm.total(PH_PLAN_K);
 }
 
 // COO (device arrays, any order) -> compressed by `seg` with ascending `inner` indices; all outputs in `sc`.
@@ -1395,6 +1508,35 @@ static void merge_record_parts_impl(Context *ctx, Result *res, uint64_t M, uint6
 static void note_variants(const Context *ctx, Result *res) {
     res->info.rank_atomic = ctx->rank_atomic ? 1u : 0u;
     res->info.dense_atomic = ctx->dense_atomic[res->dtype == OSP_F64] ? 1u : 0u;
+}
+
+// relu(C + bias) with the zeros dropped, as a new CSR (osp_epilogue.h)
+template <class T>
+static void bias_relu_impl(Context *ctx, const Result *in, Result *res, const T *bias_in, osp_memspace_t bias_space, int relu) {
+    hipStream_t s = ctx->stream;
+    Scratch sc(ctx);
+    EventPair ev;
+    OSP_HIP(hipEventRecord(ev.a, s));
+    const uint64_t M = in->info.M, N = in->info.N;
+    const T *bias = bias_in ? to_device(sc, bias_in, N, bias_space, s) : nullptr;
+    res->info = in->info;
+    res->rowptr = (int64_t *)ctx->alloc((M + 1) * sizeof(int64_t));
+    uint32_t *cnt = sc.get<uint32_t>(M + 1);
+    uint64_t *tmp = sc.get<uint64_t>(scan_scratch_entries(M + 1));
+    const unsigned grid = grid_for(std::max<uint64_t>(M, 1) * kWave, 256);
+    bias_relu_rows_kernel<T, false><<<grid, 256, 0, s>>>(in->rowptr, in->colidx, (const T *)in->vals, M, N, bias, relu, cnt, nullptr, nullptr, nullptr);
+    device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{cnt}, M, (uint64_t *)res->rowptr, tmp, s);
+    const uint64_t nnz = (uint64_t)d2h(res->rowptr + M, s);
+    res->colidx = (uint32_t *)ctx->alloc(std::max<uint64_t>(nnz, 1) * sizeof(uint32_t));
+    res->vals = ctx->alloc(std::max<uint64_t>(nnz, 1) * sizeof(T));
+    if (nnz)
+        bias_relu_rows_kernel<T, true><<<grid, 256, 0, s>>>(in->rowptr, in->colidx, (const T *)in->vals, M, N, bias, relu, nullptr, res->rowptr, res->colidx,
+                                                            (T *)res->vals);
+    OSP_HIP(hipEventRecord(ev.b, s));
+    OSP_HIP(hipStreamSynchronize(s));
+    OSP_HIP(hipGetLastError());
+    res->info.nnz_c = nnz;
+    res->info.ms_total = ev.ms();
 }
 
 static void destroy_result(Result *r) {
@@ -1799,6 +1941,47 @@ int osp_merge_record_parts(osp_context_t ctx_, osp_dtype_t dtype, uint64_t M, ui
     }
     *result = (osp_result_t)res;
     return OSP_OK;
+}
+
+int osp_csr_bias_relu(osp_result_t in_, const void *bias, osp_memspace_t bias_space, int relu, osp_result_t *out) {
+    Result *in = (Result *)in_;
+    if (!in || !out) return fail(OSP_ERR_ARG, "null argument");
+    if (in->partials) return fail(OSP_ERR_ARG, "a result of osp_spgemm_partials holds records, not a CSR");
+    if (bias_space != OSP_HOST && bias_space != OSP_DEVICE) return fail(OSP_ERR_ARG, "bad memory space");
+    Context *ctx = in->ctx;
+    Result *res = new Result;
+    res->ctx = ctx;
+    res->dtype = in->dtype;
+    try {
+        OSP_HIP(hipSetDevice(ctx->device));
+        if (in->dtype == OSP_F32) bias_relu_impl<float>(ctx, in, res, (const float *)bias, bias_space, relu);
+        else bias_relu_impl<double>(ctx, in, res, (const double *)bias, bias_space, relu);
+    } catch (const Error &e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        destroy_result(res);
+        return fail(e.status, "%s", e.what());
+    } catch (const std::exception &e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        destroy_result(res);
+        return fail(OSP_ERR_ALLOC, "%s", e.what());
+    }
+    *out = (osp_result_t)res;
+    return OSP_OK;
+}
+
+int osp_result_coo_rows(osp_result_t r_, uint32_t *rows_device) {
+    Result *r = (Result *)r_;
+    if (!r || !rows_device) return fail(OSP_ERR_ARG, "null argument");
+    if (r->partials) return fail(OSP_ERR_ARG, "a result of osp_spgemm_partials holds records, not a CSR");
+    OSP_GUARD_BEGIN
+    OSP_HIP(hipSetDevice(r->ctx->device));
+    const uint64_t M = r->info.M;
+    if (M && r->info.nnz_c)
+        csr_expand_rows_kernel<<<grid_for(M * kWave, 256), 256, 0, r->ctx->stream>>>(r->rowptr, M, rows_device);
+    OSP_HIP(hipStreamSynchronize(r->ctx->stream));
+    OSP_HIP(hipGetLastError());
+    return OSP_OK;
+    OSP_GUARD_END
 }
 
 int osp_result_info(osp_result_t r_, osp_result_info_t *info) {

@@ -9,7 +9,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "../../include/outerspace_spgemm.h"
 #include "osp_internal.h"
@@ -38,74 +44,141 @@ extern "C" {
 void osp_host_free(void *p) { free(p); }
 const char *osp_last_error_string(void) { return osp::g_last_error.c_str(); }
 
+// One line of the file, NUL-terminated in `buf` (the rules below are written for C strings; a line never reaches into
+// the next one).  Returns false for a line the reference skips (:66-77): first non-blank char is '%', or nothing but blanks.
+static inline const char *kept_line(const char *b, const char *e, std::string &buf) {
+    buf.assign(b, e);
+    const char *p = buf.c_str();
+    while (*p == ' ' || *p == '\t') p++;
+    if (*p == '%' || *p == '\0' || *p == '\n' || *p == '\r') return nullptr;
+    return p;
+}
+struct MtxPiece {   // what one thread parsed: entries of its byte range, in file order
+    std::vector<uint32_t> r, c;
+    std::vector<double> v;
+    bool bad_alloc = false;
+};
+// entries "row col [val]" of the lines that START in [b, e) (the last one may end beyond e, never beyond `end`)
+static void parse_entries(const char *b, const char *e, const char *end, int symmetric, MtxPiece &out) {
+    try {
+        std::string buf;
+        const char *p = b;
+        while (p < e) {
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+            const char *le = nl ? nl : end;
+            const char *q = kept_line(p, le, buf);
+            p = nl ? nl + 1 : end;
+            if (!q) continue;
+            // strtoull/strtod instead of sscanf: same accepted syntax, much faster
+            char *stop = nullptr;
+            unsigned long long row = strtoull(q, &stop, 10);
+            unsigned long long col = 0;
+            double val = 1.0;  // pattern entry (:92-93)
+            if (stop != q) {
+                const char *t = stop;
+                col = strtoull(t, &stop, 10);
+                if (stop != t) {
+                    t = stop;
+                    double x = strtod(t, &stop);
+                    if (stop != t) val = x;
+                }
+            }
+            out.r.push_back((uint32_t)(row - 1));  // 1-based -> 0-based (:94)
+            out.c.push_back((uint32_t)(col - 1));
+            out.v.push_back(val);
+            if (symmetric && row != col) {  // :95-96
+                out.r.push_back((uint32_t)(col - 1));
+                out.c.push_back((uint32_t)(row - 1));
+                out.v.push_back(val);
+            }
+        }
+    } catch (const std::bad_alloc &) { out.bad_alloc = true; }
+}
+
+// The reference reads its files with one thread, getline + sscanf per entry (TIMER("Read Matrix"), :844-850: minutes for
+// the 65 M lines of a scale-22 operand).  Here the file is mapped and the lines behind the header are parsed by several
+// threads, each on a byte range that starts at a line start; the pieces are concatenated in file order, so the result is
+// what the single-threaded loop gives.  OSP_PARSE_THREADS overrides the thread count (default: one per 4 MB, at most 32
+// and at most the hardware's).
 int osp_mtx_read(const char *path, int symmetric, uint64_t *nrow, uint64_t *ncol, uint64_t *nnz,
                  uint32_t **rows, uint32_t **cols, double **vals) {
     if (!path || !nrow || !ncol || !nnz || !rows || !cols || !vals) return fail(OSP_ERR_ARG, "null argument");
     *rows = nullptr; *cols = nullptr; *vals = nullptr;
     *nrow = *ncol = *nnz = 0;
-    FILE *f = fopen(path, "rb");
-    if (!f) return fail(OSP_ERR_IO, "cannot open %s", path);
-    char *line = nullptr;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(OSP_ERR_IO, "cannot open %s", path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { close(fd); return fail(OSP_ERR_IO, "cannot read %s", path); }
+    const size_t bytes = (size_t)sb.st_size;
+    const char *data = nullptr;
+    if (bytes) {
+        void *m = mmap(nullptr, bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); return fail(OSP_ERR_IO, "cannot map %s", path); }
+        data = (const char *)m;
+        (void)madvise(m, bytes, MADV_SEQUENTIAL);
+    }
+    close(fd);
     int st = OSP_OK;
-    try {  // nothing thrown by the vectors may cross the C boundary
-        std::vector<uint32_t> r, c;
-        std::vector<double> v;
-        size_t cap = 0;
-        bool header = true;
+    try {  // nothing thrown here may cross the C boundary
+        const char *end = data + bytes;
+        // the first kept line is "rows cols nnz" (:79-88)
         unsigned long long NR = 0, NC = 0, NZ = 0;
-        // an entry takes at least four bytes of the file ("1 1\n"): a header that announces more than the file can hold
-        // (or garbage) must not drive the reservation
-        unsigned long long file_bytes = 0;
-        if (fseek(f, 0, SEEK_END) == 0) { const long e = ftell(f); if (e > 0) file_bytes = (unsigned long long)e; }
-        rewind(f);
-        while (getline(&line, &cap, f) >= 0) {
-            // skip rule of the reference (:66-77): first non-blank char is '%', or nothing but blanks
-            const char *p = line;
-            while (*p == ' ' || *p == '\t') p++;
-            if (*p == '%' || *p == '\0' || *p == '\n' || *p == '\r') continue;
-            if (header) {  // :79-88
-                sscanf(p, "%llu %llu %llu", &NR, &NC, &NZ);
-                const unsigned long long want = std::min(NZ, file_bytes / 4 + 1) * (symmetric ? 2ull : 1ull);
-                r.reserve(want);
-                c.reserve(want);
-                v.reserve(want);
-                header = false;
-                continue;
-            }
-            // "row col [val]"; strtoull/strtod instead of sscanf: same accepted syntax, much faster
-            char *end = nullptr;
-            unsigned long long row = strtoull(p, &end, 10);
-            unsigned long long col = 0;
-            double val = 1.0;  // pattern entry (:92-93)
-            if (end != p) {
-                const char *q = end;
-                col = strtoull(q, &end, 10);
-                if (end != q) {
-                    q = end;
-                    double t = strtod(q, &end);
-                    if (end != q) val = t;
-                }
-            }
-            r.push_back((uint32_t)(row - 1));  // 1-based -> 0-based (:94)
-            c.push_back((uint32_t)(col - 1));
-            v.push_back(val);
-            if (symmetric && row != col) {  // :95-96
-                r.push_back((uint32_t)(col - 1));
-                c.push_back((uint32_t)(row - 1));
-                v.push_back(val);
+        const char *p = data;
+        {
+            std::string buf;
+            while (p < end) {
+                const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+                const char *q = kept_line(p, nl ? nl : end, buf);
+                p = nl ? nl + 1 : end;
+                if (q) { sscanf(q, "%llu %llu %llu", &NR, &NC, &NZ); break; }
             }
         }
-        const size_t n = r.size();
+        const size_t body = (size_t)(end - p);
+        unsigned nthreads = 1;
+        if (const char *env = getenv("OSP_PARSE_THREADS")) nthreads = (unsigned)std::max(1, atoi(env));
+        else nthreads = (unsigned)std::min<size_t>(std::min<size_t>(32, std::max(1u, std::thread::hardware_concurrency())), body / (4u << 20) + 1);
+        std::vector<MtxPiece> pieces(nthreads);
+        // an entry takes at least four bytes of the file ("1 1\n"): a header that announces more than the file can hold
+        // (or garbage) must not drive the reservation
+        const unsigned long long want = std::min<unsigned long long>(NZ, bytes / 4 + 1) * (symmetric ? 2ull : 1ull);
+        // byte ranges that start at line starts
+        std::vector<const char *> cut(nthreads + 1, end);
+        cut[0] = p;
+        for (unsigned t = 1; t < nthreads; t++) {
+            const char *c = p + body / nthreads * t;
+            if (c <= cut[t - 1]) { cut[t] = cut[t - 1]; continue; }
+            const char *nl = (const char *)memchr(c - 1, '\n', (size_t)(end - (c - 1)));   // the line break at or behind c - 1
+            cut[t] = nl ? nl + 1 : end;
+        }
+        for (unsigned t = 0; t < nthreads; t++) {
+            const size_t r = want / nthreads + 16;
+            pieces[t].r.reserve(r); pieces[t].c.reserve(r); pieces[t].v.reserve(r);
+        }
+        if (nthreads == 1) {
+            parse_entries(cut[0], cut[1], end, symmetric, pieces[0]);
+        } else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nthreads; t++)
+                th.emplace_back(parse_entries, cut[t], cut[t + 1], end, symmetric, std::ref(pieces[t]));
+            for (auto &x : th) x.join();
+        }
+        size_t n = 0;
+        for (auto &pc : pieces) { if (pc.bad_alloc) throw std::bad_alloc(); n += pc.r.size(); }
         *rows = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
         *cols = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
         *vals = (double *)malloc((n ? n : 1) * sizeof(double));
         if (!*rows || !*cols || !*vals) {
             st = fail(OSP_ERR_ALLOC, "host allocation failed");
         } else {
-            if (n) {
-                memcpy(*rows, r.data(), n * sizeof(uint32_t));
-                memcpy(*cols, c.data(), n * sizeof(uint32_t));
-                memcpy(*vals, v.data(), n * sizeof(double));
+            size_t o = 0;
+            for (auto &pc : pieces) {
+                const size_t m = pc.r.size();
+                if (m) {
+                    memcpy(*rows + o, pc.r.data(), m * sizeof(uint32_t));
+                    memcpy(*cols + o, pc.c.data(), m * sizeof(uint32_t));
+                    memcpy(*vals + o, pc.v.data(), m * sizeof(double));
+                }
+                o += m;
             }
             *nrow = NR; *ncol = NC; *nnz = n;
         }
@@ -114,8 +187,7 @@ int osp_mtx_read(const char *path, int symmetric, uint64_t *nrow, uint64_t *ncol
     } catch (const std::exception &e) {
         st = fail(OSP_ERR_ALLOC, "%s while reading %s", e.what(), path);
     }
-    free(line);
-    fclose(f);
+    if (data) (void)munmap((void *)data, bytes);
     if (st != OSP_OK) {  // hand nothing half-made to the caller
         free(*rows); free(*cols); free(*vals);
         *rows = nullptr; *cols = nullptr; *vals = nullptr;

@@ -43,6 +43,12 @@ constexpr int kMulBatchAvg = 64;  // ... and at most this many per column on ave
 #ifndef OSP_MUL_TILE_MIN
 #define OSP_MUL_TILE_MIN 1024
 #endif
+#ifndef OSP_MUL_QU_MID
+#define OSP_MUL_QU_MID 4
+#endif
+#ifndef OSP_MUL_QU_HUB
+#define OSP_MUL_QU_HUB 2
+#endif
 constexpr int kMulTileMin = OSP_MUL_TILE_MIN;  // B rows from this length on: products numbered in panels of the row (multiply_kernel)
 constexpr int kMulTileW = 128;                 // ... of this many entries (256: 77 registers, slower everywhere; 64: slower at Graph500 skew)
 
@@ -257,6 +263,60 @@ __device__ __forceinline__ double wave_bcast(double v, uint32_t src) {
     return __longlong_as_double((long long)wave_bcast((uint64_t)__double_as_longlong(v), src));
 }
 
+// ---- long rows written straight into their column ranges ("direct" rows) ----------------------------------------------
+// A long output row (more partial products than one merge tile) must reach the tile kernel cut into column ranges.  The
+// split kernels (osp_split.h) do that with an extra read-read-write pass over the row's records.  For a DIRECT row the
+// multiply phase itself puts every product where the split would have moved it: the planner (direct_plan_kernel,
+// osp_split.h) cuts the row's columns into ranges of at most one tile from an exact histogram, and stores for every chunk
+// (non-zero A[i,k]) and range the position of the chunk's run inside that range -- ranges in column order, inside a range
+// the runs in chunk order (ascending k), inside a run ascending columns: exactly the order the stable split produces, so
+// the sums keep their bits.  chunk_off[e] of such a chunk is a descriptor instead of a staging offset:
+//   bit 63 | shift (5 bits) | first cell of the chunk, in words from the row's block (26 bits) | the row's block (32 bits)
+// and the row's block in `cells` is   [ range of every fine column bin: nfine bytes ][ chunk 0: one word per range ] ...
+// A product (chunk, l-th entry of B's row, column c) goes to record  cell[range(c >> shift)] + l  of the second buffer
+// (32-bit arithmetic; the cell holds the run's start minus the index of the run's first entry).
+constexpr uint64_t kDirectBit = 1ull << 63;
+__device__ __forceinline__ uint64_t direct_desc(uint32_t rowbase, uint32_t celloff, uint32_t sh) {
+    return kDirectBit | ((uint64_t)(sh & 31u) << 58) | ((uint64_t)(celloff & 0x3ffffffu) << 32) | (uint64_t)rowbase;
+}
+template <class T>
+__device__ __forceinline__ void store_direct(const uint32_t *__restrict__ cells, Part<T> *__restrict__ qstage, uint64_t desc, uint32_t l,
+                                             uint32_t bc, T v) {
+    const uint32_t *rb = cells + (uint32_t)desc;
+    const uint32_t sh = (uint32_t)(desc >> 58) & 31u, co = (uint32_t)(desc >> 32) & 0x3ffffffu;
+    const uint32_t rg = reinterpret_cast<const uint8_t *>(rb)[bc >> sh];
+    const uint32_t delta = rb[co + rg];
+    stream_store_part(&qstage[(uint32_t)(delta + l)], bc, v);
+}
+
+// Where ONE entry of B's row (index ld in the row, column bc) goes in QU chunks at once.  off[i]: the chunk's staging
+// offset (wave-uniform; the entry's position in the chunk is lp behind it) or its descriptor.  A direct chunk costs two
+// dependent loads per entry (range of the column, cell of the range); written one chunk after the other, every store
+// waits for both, and that latency -- not bandwidth -- bounds the kernel (R-MAT-22: 10.1 -> 17.3 ms per launch).  Here the
+// loads of all QU chunks go out together, branch-free (a chunk that is not direct reads a word of `safe` and ignores it).
+template <class T, int QU>
+__device__ __forceinline__ void chunk_dests(const uint32_t *__restrict__ cells, const void *safe, Part<T> *__restrict__ stage,
+                                            Part<T> *__restrict__ qstage, const uint64_t (&off)[QU], uint32_t lp, uint32_t ld,
+                                            uint32_t bc, Part<T> *(&dst)[QU]) {
+    const uint32_t *rb[QU];
+    uint32_t rg[QU], delta[QU];
+    bool dir[QU];
+#pragma unroll
+    for (int i = 0; i < QU; i++) {
+        dir[i] = (off[i] & kDirectBit) && off[i] != kChunkSkip;   // (wave-uniform)
+        rb[i] = dir[i] ? cells + (uint32_t)off[i] : reinterpret_cast<const uint32_t *>(safe);
+        const uint32_t sh = (uint32_t)(off[i] >> 58) & 31u;
+        rg[i] = reinterpret_cast<const uint8_t *>(rb[i])[dir[i] ? bc >> sh : 0u];
+    }
+#pragma unroll
+    for (int i = 0; i < QU; i++) {
+        const uint32_t co = (uint32_t)(off[i] >> 32) & 0x3ffffffu;
+        delta[i] = rb[i][dir[i] ? co + rg[i] : 0u];
+    }
+#pragma unroll
+    for (int i = 0; i < QU; i++) dst[i] = dir[i] ? &qstage[(uint32_t)(delta[i] + ld)] : &stage[off[i] + lp];
+}
+
 // ---- multiply ----------------------------------------------------------------------------------
 // Reference: cscMulcsr, SimSpGEMM.cpp:265-281.  The panel's products are numbered k-major,
 // then by A entry j, then by B entry l; wave `wv` owns products [wv*kMulPerWave, ...).  For each
@@ -268,7 +328,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
     const int64_t *__restrict__ b_rowptr, const uint64_t *__restrict__ chunk_off, int64_t e0,
     const int64_t *__restrict__ a_start, const uint32_t *__restrict__ a_cnt,
     const uint64_t *__restrict__ prod_off, uint64_t k0, uint64_t nk, uint64_t total, uint64_t base,
-    Part<T> *__restrict__ stage) {
+    Part<T> *__restrict__ stage, const uint32_t *__restrict__ cells = nullptr, Part<T> *__restrict__ qstage = nullptr) {
     const unsigned lane = lane_id();
     const uint64_t wv = (uint64_t)blockIdx.x * (kMulThreads / kWave) + (threadIdx.x >> 6);
     const uint64_t ws = wv * kMulPerWave;
@@ -329,7 +389,10 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                         const uint64_t raw = chunk_off[e - (uint64_t)e0];
                         const uint32_t bc = b_colidx[bsx + l];
                         const T pv = a_vals[e] * b_vals[bsx + l];
-                        if (raw != kChunkSkip) stream_store_part(&stage[raw - base + l], bc, pv);
+                        if (raw != kChunkSkip) {
+                            if (raw & kDirectBit) store_direct(cells, qstage, raw, l, bc, pv);
+                            else stream_store_part(&stage[raw - base + l], bc, pv);
+                        }
                     }
                 }
                 cur = p0 + hi_p;
@@ -383,19 +446,32 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                     if (jm <= tj1) {
                         av_l = a_vals[as + jm];
                         const uint64_t raw = chunk_off[as + jm - (uint64_t)e0];
-                        off_l = raw == kChunkSkip ? kChunkSkip : raw - base + (uint64_t)pnl * W;
+                        off_l = (raw & kDirectBit) ? raw : raw - base + (uint64_t)pnl * W;  // (kChunkSkip and descriptors: as they are)
                     }
                     const uint32_t cj = (uint32_t)min((uint64_t)kWave, tj1 - jb + 1);
-                    for (uint32_t q = 0; q < cj; q++) {
-                        const uint64_t j = jb + q;
-                        const T av = wave_bcast(av_l, q);
-                        const uint64_t off = wave_bcast(off_l, q);
-                        if (off == kChunkSkip) continue;
-                        const uint32_t lo = j == tj0 ? tla : 0u, hi = j == tj1 ? tlb : wp;
+                    constexpr int QU = OSP_MUL_QU_HUB;   // chunks whose destinations are formed together (chunk_dests): with two entries per lane, twice as many chains
+                    for (uint32_t q = 0; q < cj; q += QU) {
+                        uint64_t off[QU];
+                        T av[QU];
+                        uint32_t lo[QU], hi[QU];
+#pragma unroll
+                        for (int i = 0; i < QU; i++) {
+                            const bool there = q + i < cj;
+                            const uint32_t qi = there ? q + i : q;
+                            const uint64_t j = jb + qi;
+                            av[i] = wave_bcast(av_l, qi);
+                            off[i] = there ? wave_bcast(off_l, qi) : kChunkSkip;
+                            lo[i] = j == tj0 ? tla : 0u;
+                            hi[i] = off[i] == kChunkSkip ? 0u : (j == tj1 ? tlb : wp);   // (a skipped chunk: no lane in range)
+                        }
 #pragma unroll
                         for (uint32_t u = 0; u < PER; u++) {
                             const uint32_t lrel = u * kWave + lane;
-                            if (lrel >= lo && lrel < hi) stream_store_part(&stage[off + lrel], bc[u], av * bv[u]);
+                            Part<T> *dst[QU];
+                            chunk_dests<T, QU>(cells, chunk_off, stage, qstage, off, lrel, pnl * W + lrel, bc[u], dst);
+#pragma unroll
+                            for (int i = 0; i < QU; i++)
+                                if (lrel >= lo[i] && lrel < hi[i]) stream_store_part(dst[i], bc[u], av[i] * bv[u]);
                         }
                     }
                 }
@@ -411,7 +487,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                 if (jm <= j1) {
                     av_l = a_vals[as + jm];
                     const uint64_t raw = chunk_off[as + jm - (uint64_t)e0];
-                    off_l = raw == kChunkSkip ? kChunkSkip : raw - base;
+                    off_l = (raw & kDirectBit) ? raw : raw - base;  // (kChunkSkip and descriptors: as they are)
                 }
                 const uint32_t cj = (uint32_t)min((uint64_t)kWave, j1 - jb + 1);
                 for (uint32_t l0 = 0; l0 < nb; l0 += kWave) {
@@ -419,12 +495,25 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                     const bool in = l < nb;
                     uint32_t bc = 0; T bv = 0;
                     if (in) { bc = b_colidx[bs + l]; bv = b_vals[bs + l]; }
-                    for (uint32_t q = 0; q < cj; q++) {
-                        const uint64_t j = jb + q;
-                        const T av = wave_bcast(av_l, q);
-                        const uint64_t off = wave_bcast(off_l, q);
-                        const bool ok = in && off != kChunkSkip && !(j == j0 && l < la) && !(j == j1 && l >= lb);
-                        if (ok) stream_store_part(&stage[off + l], bc, av * bv);
+                    constexpr int QU = OSP_MUL_QU_MID;   // chunks whose destinations are formed together (chunk_dests)
+                    for (uint32_t q = 0; q < cj; q += QU) {
+                        uint64_t off[QU];
+                        T av[QU];
+                        bool ok[QU];
+                        Part<T> *dst[QU];
+#pragma unroll
+                        for (int i = 0; i < QU; i++) {
+                            const bool there = q + i < cj;
+                            const uint32_t qi = there ? q + i : q;
+                            const uint64_t j = jb + qi;
+                            av[i] = wave_bcast(av_l, qi);
+                            off[i] = there ? wave_bcast(off_l, qi) : kChunkSkip;
+                            ok[i] = in && off[i] != kChunkSkip && !(j == j0 && l < la) && !(j == j1 && l >= lb);
+                        }
+                        chunk_dests<T, QU>(cells, chunk_off, stage, qstage, off, l, l, bc, dst);
+#pragma unroll
+                        for (int i = 0; i < QU; i++)
+                            if (ok[i]) stream_store_part(dst[i], bc, av[i] * bv);
                     }
                 }
             }
@@ -442,7 +531,10 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                 if (ok) {
                     const uint64_t e = as + j;
                     const uint64_t raw = chunk_off[e - (uint64_t)e0];
-                    if (raw != kChunkSkip) stream_store_part(&stage[raw - base + l], bc, a_vals[e] * bv);
+                    if (raw != kChunkSkip) {
+                        if (raw & kDirectBit) store_direct(cells, qstage, raw, l, bc, a_vals[e] * bv);
+                        else stream_store_part(&stage[raw - base + l], bc, a_vals[e] * bv);
+                    }
                 }
             }
         }
@@ -703,7 +795,7 @@ struct MergeLevels {
 template <int CAP>
 __global__ void tile_desc_kernel(const uint32_t *tile_rows, uint32_t ntiles, uint64_t r_end, const uint64_t *row_off,
                                  uint64_t base, uint32_t lvl, const uint32_t *j0, const uint32_t *extra, uint32_t nlong,
-                                 const uint32_t *tb, int colbits, const uint8_t *hbits, const uint64_t *vbase, TileDesc *desc) {
+                                 const uint32_t *tb, const uint32_t *vcol0, const uint32_t *vcol1, TileDesc *desc) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
     const uint64_t ra = tile_rows[t], rb = (t + 1 < ntiles) ? (uint64_t)tile_rows[t + 1] : r_end;
@@ -724,9 +816,9 @@ __global__ void tile_desc_kernel(const uint32_t *tile_rows, uint32_t ntiles, uin
         } else {
             const uint32_t h = (uint32_t)(upper_bound_dev(tb, 0, (uint64_t)nlong + 1, t) - 1);  // owner long row
             pos = j0[h] + extra[h] + (t - tb[h]);
-            const int sh = colbits - (int)hbits[h];              // log2 of a segment's column range
-            d.cbase = (uint32_t)((ra - vbase[h]) << sh);
-            const uint64_t range = (uint64_t)d.nr << sh;
+            // the tile's segments are consecutive column ranges of one long row: [vcol0[ra], vcol1[rb - 1])
+            d.cbase = vcol0[ra];
+            const uint64_t range = (uint64_t)(vcol1[rb - 1] - vcol0[ra]);
             int kb = 1;
             while (kb < 32 && (1ull << kb) < range) kb++;
             d.kbits = (uint32_t)kb;
@@ -1387,21 +1479,22 @@ __global__ void seg_partition_kernel(SegHugeFlag f, const uint32_t *scan, uint32
     if (f(t)) huge[scan[t]] = f.list[t]; else mid[t - scan[t]] = f.list[t];
 }
 // one in-place tile per mid-sized over-long segment v: key = col - first column of the segment
-__global__ void seg_tile_desc_kernel(const uint32_t *mid, uint32_t nmid, const uint64_t *vrow_off, const uint64_t *vbase,
-                                     const uint8_t *hbits, uint32_t nlong, int colbits, TileDesc *desc) {
+__global__ void seg_tile_desc_kernel(const uint32_t *mid, uint32_t nmid, const uint64_t *vrow_off, const uint32_t *vcol0,
+                                     const uint32_t *vcol1, TileDesc *desc) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nmid) return;
     const uint32_t v = mid[t];
-    const uint32_t h = (uint32_t)(upper_bound_dev(vbase, 0, (uint64_t)nlong + 1, (uint64_t)v) - 1);  // owner long row
-    const int sh = colbits - (int)hbits[h];
     TileDesc d;
     d.s = vrow_off[v];
     d.ra = v;
     d.nr = 1;
     d.n = (uint32_t)(vrow_off[v + 1] - vrow_off[v]);
     d.lvl = 1;
-    d.cbase = (uint32_t)((v - vbase[h]) << sh);
-    d.kbits = (uint32_t)(sh < 1 ? 1 : sh);
+    d.cbase = vcol0[v];
+    const uint64_t range = (uint64_t)(vcol1[v] - vcol0[v]);
+    int kb = 1;
+    while (kb < 32 && (1ull << kb) < range) kb++;
+    d.kbits = (uint32_t)kb;
     desc[t] = d;
 }
 

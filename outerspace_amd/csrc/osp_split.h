@@ -53,9 +53,23 @@ constexpr int kSplitTarget = OSP_SPLIT_TARGET;     // aim for segments of about 
 constexpr int kSplitRowBits = OSP_SPLIT_ROW_BITS;      // rows of at most 2^9 segments (<= 128K entries) are split by ONE workgroup (8: +0.8 %, 10: slower)
 constexpr uint64_t kSplitRowMax = (uint64_t)kSplitTarget << kSplitRowBits;  // longer rows: one workgroup per stretch
 
-// per long row h: b = number of split bits, and the sizes that get scanned
+// How a long row reaches the tile kernel (hmode):
+//   kModeSplitRow  one workgroup moves it into 2^b column ranges of the second buffer (split_row_kernel)
+//   kModeStretch   too long for that: one workgroup per stretch, offsets from a device-wide scan (split_count / split_scatter)
+//   kModeDirect    the multiply phase writes it into the second buffer range by range (direct_plan_kernel + store_direct,
+//                  osp_kernels.h): no pass over its records at all
+constexpr uint8_t kModeSplitRow = 0, kModeStretch = 1, kModeDirect = 2;
+constexpr int kDirectThreads = 256;
+constexpr int kDirectCells = 4096;     // LDS words of direct_plan_kernel's (chunk, range) cells: counts and in-chunk starts
+constexpr int kDirectMaxRanges = 255;  // ranges per direct row (a byte per fine bin names the range)
+// per long row h: b = number of split bits, the mode, and the sizes that get scanned.
+// rowfirst != nullptr: the row's chunks are known (first chunk of every row in (row, k) order), so rows of at most
+// direct_max partial products that one workgroup could split are planned as direct rows instead: nseg = an upper bound
+// of their ranges (consecutive ranges of the greedy grouping together exceed a tile, hence <= 2U/cap + 1 of them),
+// ncell = words of their block in the cell array.
 __global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *row_off, int colbits,
-                                    uint64_t row_max, int bits_cap, uint8_t *hbits, uint32_t *nstretch, uint32_t *nseg, uint64_t *nhist) {
+                                    uint64_t row_max, int bits_cap, const uint32_t *rowfirst, uint64_t direct_max, uint32_t cap,
+                                    uint8_t *hbits, uint8_t *hmode, uint32_t *nstretch, uint32_t *nseg, uint64_t *nhist, uint64_t *ncell) {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= nheavy) return;
     const uint64_t U = row_off[rows[h] + 1] - row_off[rows[h]];
@@ -65,11 +79,23 @@ __global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const
     b = min(b, min(colbits, bits_cap));
     const bool big = U > row_max || b > kSplitRowBits;
     const uint32_t ns = big ? (uint32_t)((U + kSplitJob - 1) / kSplitJob) : 0u;  // 0 stretches = one-workgroup row
+    const uint64_t nranges = 2 * U / cap + 2;
+    const bool direct = rowfirst != nullptr && !big && U <= direct_max && nranges <= (uint64_t)kDirectMaxRanges;
     hbits[h] = (uint8_t)b;
+    hmode[h] = direct ? kModeDirect : big ? kModeStretch : kModeSplitRow;
     nstretch[h] = ns;
-    nseg[h] = 1u << b;
+    nseg[h] = direct ? (uint32_t)nranges : 1u << b;
     nhist[h] = (uint64_t)ns << b;
+    const uint64_t nc = direct ? (uint64_t)(rowfirst[rows[h] + 1] - rowfirst[rows[h]]) : 0ull;
+    ncell[h] = direct ? ((1ull << b) + 3) / 4 + nc * nranges : 0ull;
 }
+struct HeavyLenIf {   // partial products of long row h if it has mode `mode` (else 0): how much each path handles
+    const uint32_t *rows;
+    const uint64_t *row_off;
+    const uint8_t *hmode;
+    uint8_t mode;
+    __device__ uint64_t operator()(uint64_t h) const { return hmode[h] == mode ? row_off[rows[h] + 1] - row_off[rows[h]] : 0ull; }
+};
 struct LoadU32As64 {
     const uint32_t *p;
     __device__ uint64_t operator()(uint64_t i) const { return p[i]; }
@@ -217,15 +243,21 @@ __global__ __launch_bounds__(kSplitThreads) void split_scatter_kernel(
 }
 
 // segment v of the split = "virtual row": its offset in the second buffer
+// ... and the columns it covers, [vcol0[v], vcol1[v]) (the segments of a direct row: written by its planner)
 __global__ void split_vrows_kernel(uint32_t nheavy, const uint64_t *vbase, const uint64_t *hbase, const uint32_t *nstretch,
+                                   const uint8_t *hbits, const uint8_t *hmode, int colbits,
                                    const uint32_t *goffs, const uint64_t *hoff, uint64_t nvirt, uint64_t nh_total,
-                                   uint64_t *vrow_off, uint8_t *vfirst) {
+                                   uint64_t *vrow_off, uint8_t *vfirst, uint32_t *vcol0, uint32_t *vcol1) {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v > nvirt) return;
     if (v == nvirt) { vrow_off[v] = nh_total; vfirst[v] = 1; return; }
     const uint32_t h = (uint32_t)(upper_bound_dev(vbase, 0, (uint64_t)nheavy + 1, v) - 1);
     const uint64_t d = v - vbase[h];
     vfirst[v] = d == 0;  // first segment of a long row: a tile must start here
+    if (hmode[h] == kModeDirect) return;
+    const int sh = colbits - (int)hbits[h];
+    vcol0[v] = (uint32_t)(d << sh);
+    vcol1[v] = (uint32_t)min((d + 1) << sh, (uint64_t)0xffffffffu);  // (columns are below 2^32 - 1)
     if (nstretch[h] == 0) return;  // one-workgroup row: split_row_kernel wrote its segment offsets
     vrow_off[v] = hoff[h] + (goffs[hbase[h] + d * nstretch[h]] - goffs[hbase[h]]);
 }
@@ -249,15 +281,12 @@ constexpr int kDenseBits = OSP_DENSE_BITS;  // segments whose column range is at
 constexpr int kDenseWaves = kDenseBits <= 12 ? 4 : (kDenseBits == 13 ? 2 : 1);
 struct SegDenseFlag {
     const uint32_t *list;   // over-long segments (virtual rows)
-    const uint64_t *vbase;  // first segment of every long row
-    const uint8_t *hbits;   // split bits of every long row
-    uint32_t nlong;
-    int colbits, enabled;
+    const uint32_t *vcol0, *vcol1;  // the columns every segment covers
+    int enabled;
     __device__ uint32_t operator()(uint64_t t) const {
         if (!enabled) return 0u;
         const uint32_t v = list[t];
-        const uint32_t h = (uint32_t)(upper_bound_dev(vbase, 0, (uint64_t)nlong + 1, (uint64_t)v) - 1);
-        return (colbits - (int)hbits[h]) <= kDenseBits ? 1u : 0u;
+        return (vcol1[v] - vcol0[v]) <= (1u << kDenseBits) ? 1u : 0u;
     }
 };
 // Does one ds_add_f64 apply the lanes that hit the same address in ascending lane order?  Every wave adds 64 values of
@@ -317,7 +346,7 @@ __global__ void seg_split_list_kernel(F f, const uint32_t *scan, uint32_t n, uin
 // later entries.
 template <class T, bool FA = false>
 __global__ __launch_bounds__(kDenseWaves * kWave) void dense_segment_kernel(const uint32_t *list, uint32_t nlist, const uint64_t *vrow_off,
-                                                                          const uint64_t *vbase, const uint8_t *hbits, uint32_t nlong, int colbits,
+                                                                          const uint32_t *vcol0, const uint32_t *vcol1,
                                                                           Part<T> *qstage, uint32_t *seg_nnz) {
     constexpr int NW = kDenseWaves, R_MAX = 1 << kDenseBits;
     __shared__ T acc[NW][R_MAX];
@@ -326,11 +355,11 @@ __global__ __launch_bounds__(kDenseWaves * kWave) void dense_segment_kernel(cons
     const uint32_t idx = blockIdx.x * NW + w;
     if (idx >= nlist) return;  // (no workgroup barrier below: the waves are independent)
     const uint32_t v = list[idx];
-    const uint32_t h = (uint32_t)(upper_bound_dev(vbase, 0, (uint64_t)nlong + 1, (uint64_t)v) - 1);
-    const int sh = colbits - (int)hbits[h];
-    const uint32_t cbase = (uint32_t)((v - vbase[h]) << sh), R = 1u << sh;
+    const uint32_t cbase = vcol0[v], R = vcol1[v] - cbase;   // (<= 2^kDenseBits: SegDenseFlag)
+    int sh = 0;                                              // bits that hold a column relative to cbase
+    while ((1u << sh) < R) sh++;
     const uint64_t s0 = vrow_off[v], m = vrow_off[v + 1] - s0;
-    for (uint32_t c = lane; c < R / 32 + (R < 32 ? 1u : 0u); c += kWave) seen[w][c] = 0u;
+    for (uint32_t c = lane; c < (R + 31) / 32; c += kWave) seen[w][c] = 0u;
     constexpr bool ATOMIC = FA;
     if constexpr (ATOMIC) {
         for (uint32_t c = lane; c < R; c += kWave) acc[w][c] = T(-0.0);
@@ -409,7 +438,7 @@ __global__ __launch_bounds__(kDenseWaves * kWave) void dense_segment_kernel(cons
 //     (-DOSP_SPLIT_ROW_PRE=2, 62 registers): 16.5 ms -- no further gain, the read volume is no longer what it waits for.
 template <class T, bool RA>
 __global__ __launch_bounds__(kSplitRowThreads) void split_row_kernel(
-    const uint32_t *rows, uint32_t nheavy, const uint8_t *hbits, const uint32_t *nstretch, const uint64_t *vbase,
+    const uint32_t *rows, uint32_t nheavy, const uint8_t *hbits, const uint8_t *hmode, const uint64_t *vbase,
     const uint64_t *hoff, const uint64_t *row_off, uint64_t base, int colbits, const Part<T> *stage, Part<T> *qstage,
     uint64_t *vrow_off) {
     constexpr int NW = kSplitRowThreads / kWave;
@@ -420,7 +449,7 @@ __global__ __launch_bounds__(kSplitRowThreads) void split_row_kernel(
     __shared__ uint32_t segoff[NSEG];  // histogram, then running offset of every segment
     __shared__ uint32_t scratch[NW + 1];
     const uint32_t h = blockIdx.x;
-    if (h >= nheavy || nstretch[h] != 0) return;
+    if (h >= nheavy || hmode[h] != kModeSplitRow) return;
     const unsigned lane = lane_id(), w = threadIdx.x >> 6;
     const uint32_t b = hbits[h], nseg = 1u << b;
     const int sh = colbits - (int)b;
@@ -528,6 +557,221 @@ __global__ __launch_bounds__(kSplitRowThreads) void split_row_kernel(
         __syncthreads();
         for (uint32_t d = threadIdx.x; d < nseg; d += kSplitRowThreads) segoff[d] += cnt[NW][d];
         // (the zeroing of cnt at the top of the next round touches the same d from the same thread)
+    }
+}
+// ---- direct rows: the plan the multiply phase writes by ------------------------------------------------------------------
+// One workgroup per direct row (hmode == kModeDirect).  The row's chunks -- one per non-zero A[i,k], in ascending k -- and
+// the B rows they multiply are known from the symbolic phase (the chunk table); nothing of the row has been computed yet.
+//   1. exact histogram of the row's product columns over the 2^b fine bins (col >> sh) the split would use: B's column
+//      indices are read chunk by chunk (runs of equal bins inside a wave-load are added by their first lane);
+//   2. consecutive bins are grouped greedily into RANGES of at most `cap` products (a bin that exceeds `cap` alone is a
+//      range of its own: an over-long segment for the paths that handle those) -> the row's segments: offsets in the second
+//      buffer, column bounds, and the byte table bin -> range;
+//   3. the chunks are walked again, a block of them at a time: per (chunk, range) the number of its entries (cells in
+//      LDS), row prefixes (where the range starts inside the chunk) and column prefixes carried from block to block
+//      (where the chunk's run starts inside the range) -> the cell the multiply adds an entry's index to.
+// Ranges of one row stay in column order, runs inside a range in chunk order (ascending k), entries inside a run in
+// column order: the layout a stable split of the k-ordered row would give.
+// head lanes of the runs of equal `key` among the valid lanes of a wave-load, and each run's length
+__device__ __forceinline__ bool wave_run_head(uint32_t key, bool valid, uint32_t &runlen) {
+    const unsigned lane = lane_id();
+    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
+    const bool head = valid && (lane == 0 || key != prev);
+    const uint64_t heads = __ballot(head), vm = __ballot(valid);
+    const uint64_t rest = lane == 63 ? 0ull : (heads >> (lane + 1));
+    const uint32_t next = rest ? lane + 1 + (uint32_t)__builtin_ctzll(rest) : (uint32_t)__popcll(vm);  // valid lanes are a prefix
+    runlen = next - lane;
+    return head;
+}
+// The row's chunks are taken a block at a time: their B rows and entry counts go to LDS (one coalesced load), a scan
+// turns the counts into a flat numbering of the block's entries, and the workgroup's threads walk that numbering -- four
+// wave-loads of B's column indices in flight per wave, whatever the chunk lengths (a wave per chunk waited for two
+// dependent loads per chunk: 24 ms per launch on R-MAT-22 instead of 3).
+#ifndef OSP_DIRECT_UNR
+#define OSP_DIRECT_UNR 8
+#endif
+constexpr int kDirectChunkBlock = 512;    // chunks of a row whose descriptors sit in LDS at a time
+// first index c in [0, n) with cst[c + 1] > i   (cst ascending, cst[n] > i)
+__device__ __forceinline__ uint32_t direct_find_chunk(const uint32_t *cst, uint32_t n, uint32_t i) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cst[mid] <= i) lo = mid; else hi = mid; }
+    return lo;
+}
+__global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
+    const uint32_t *__restrict__ rows, uint32_t nlong, const uint8_t *__restrict__ hmode, const uint8_t *__restrict__ hbits,
+    const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ vbase, const uint64_t *__restrict__ hoff,
+    const uint64_t *__restrict__ cellbase, const uint64_t *__restrict__ row_off, int colbits, uint32_t cap,
+    const uint32_t *__restrict__ rowfirst, const uint64_t *__restrict__ ct_off, const uint32_t *__restrict__ ct_bs,
+    const uint32_t *__restrict__ perm, const uint32_t *__restrict__ b_colidx, uint64_t *__restrict__ vrow_off,
+    uint32_t *__restrict__ vcol0, uint32_t *__restrict__ vcol1, uint32_t *__restrict__ cells, uint64_t *__restrict__ chunk_off) {
+    constexpr int NT = kDirectThreads, NFINE = 1 << kSplitRowBits, CBL = kDirectChunkBlock, UNR = OSP_DIRECT_UNR;
+    constexpr int kCellsLds = kDirectCells / 4;
+    __shared__ uint32_t hist[NFINE + 1];     // bin counts, then their exclusive prefix
+    __shared__ uint16_t nxt[NFINE];          // first bin of the range that follows a range starting at this bin
+    __shared__ uint8_t lut[NFINE];
+    __shared__ uint32_t rbin0[kDirectMaxRanges + 2], roff[kDirectMaxRanges + 2], cursor[kDirectMaxRanges + 1];
+    __shared__ uint32_t cbs[CBL], cst[CBL + 1];
+    __shared__ uint32_t cellm[kCellsLds], lsm[kCellsLds];
+    __shared__ uint32_t psum[NT];
+    __shared__ uint32_t scratch[NT / kWave + 1];
+    __shared__ uint32_t s_T;
+    const uint32_t h = blockIdx.x;
+    if (h >= nlong || hmode[h] != kModeDirect) return;
+    const unsigned tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const uint32_t i = rows[h];
+    const uint32_t c0 = rowfirst[i], nc = rowfirst[i + 1] - c0;
+    const uint32_t b = hbits[h], nfine = 1u << b, Ta = nseg[h];
+    const int sh = colbits - (int)b;
+    const uint32_t q0 = (uint32_t)hoff[h];   // the row's first record in the second buffer (the buffer holds < 2^32)
+    uint32_t *__restrict__ rb = cells + cellbase[h];
+    const uint32_t lutw = (nfine + 3) / 4;
+    // descriptors of chunks [cb, cb + nb) -> cbs / cst (cst[nb] = entries of the block)
+    auto load_block = [&](uint32_t cb, uint32_t nb) {
+        uint32_t len[CBL / NT], sum = 0;
+#pragma unroll
+        for (int q = 0; q < CBL / NT; q++) {
+            const uint32_t j = tid * (CBL / NT) + q;   // blocked: a thread owns consecutive chunks
+            len[q] = 0;
+            if (j < nb) {
+                const uint32_t c = c0 + cb + j;
+                cbs[j] = ct_bs[c];
+                len[q] = (uint32_t)(ct_off[c + 1] - ct_off[c]);
+            }
+            sum += len[q];
+        }
+        uint32_t total;
+        uint32_t ex = block_excl_scan<uint32_t, NT>(sum, scratch, &total);
+#pragma unroll
+        for (int q = 0; q < CBL / NT; q++) {
+            const uint32_t j = tid * (CBL / NT) + q;
+            if (j < nb) cst[j] = ex;
+            ex += len[q];
+        }
+        if (tid == 0) cst[nb] = total;
+        __syncthreads();
+        return total;
+    };
+    // walks the block's entries; f(chunk in block, column, valid) is called with whole waves, valid lanes a prefix
+    auto for_entries = [&](uint32_t nb, uint32_t E, auto f) {
+        for (uint32_t base = w * (UNR * kWave); base < E; base += NT * UNR) {
+            uint32_t cu[UNR], col[UNR];
+            uint32_t c = direct_find_chunk(cst, nb, base);   // (wave-uniform)
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const uint32_t e = base + u * kWave + lane;
+                const bool valid = e < E;
+                while (valid && e >= cst[c + 1]) c++;
+                cu[u] = c;
+                col[u] = b_colidx[valid ? cbs[c] + (e - cst[c]) : 0u];   // clamped: the loads go out together
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) f(cu[u], col[u], base + u * kWave + lane < E);
+        }
+    };
+    for (uint32_t d = tid; d <= nfine; d += NT) hist[d] = 0;
+    __syncthreads();
+    // ---- 1. histogram over the fine bins
+    uint32_t have_cb = 0, have_nb = 0, have_E = 0;   // the block of chunks whose descriptors are in LDS
+    for (uint32_t cb = 0; cb < nc; cb += CBL) {
+        const uint32_t nb = min((uint32_t)CBL, nc - cb);
+        const uint32_t E = load_block(cb, nb);
+        have_cb = cb; have_nb = nb; have_E = E;
+        for_entries(nb, E, [&](uint32_t, uint32_t col, bool valid) {
+            const uint32_t bin = valid ? col >> sh : 0xffffffffu;
+            uint32_t runlen;
+            if (wave_run_head(bin, valid, runlen)) atomicAdd(&hist[bin], runlen);
+        });
+        __syncthreads();   // before the next block's descriptors replace these
+    }
+    // ---- 2. greedy grouping into ranges of at most `cap`: prefix sums, the bin every range starting at d ends before,
+    // then one thread follows that chain (a few steps instead of one per bin)
+    {
+        const uint32_t v0 = 2 * tid < nfine ? hist[2 * tid] : 0u, v1 = 2 * tid + 1 < nfine ? hist[2 * tid + 1] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan<uint32_t, NT>(v0 + v1, scratch, &total);
+        if (2 * tid < nfine) hist[2 * tid] = ex;
+        if (2 * tid + 1 < nfine) hist[2 * tid + 1] = ex + v0;
+        if (tid == 0) hist[nfine] = total;
+    }
+    __syncthreads();
+    for (uint32_t d = tid; d < nfine; d += NT) {
+        // the range that starts at bin d holds bins [d, e): the largest e with hist[e] - hist[d] <= cap, but at least one bin
+        const uint32_t lim = hist[d] + cap;
+        uint32_t lo = d + 1, hi = nfine + 1;   // first e in (d, nfine] with hist[e] > lim, or nfine + 1
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (hist[mid] <= lim) lo = mid + 1; else hi = mid; }
+        nxt[d] = (uint16_t)max(d + 1, lo - 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t t = 0;
+        for (uint32_t d = 0; d < nfine; d = nxt[d]) { rbin0[t] = d; roff[t] = hist[d]; t++; }
+        rbin0[t] = nfine; roff[t] = hist[nfine];
+        s_T = t;
+    }
+    __syncthreads();
+    const uint32_t T = s_T;   // <= Ta - 1 (split_params_kernel's bound)
+    for (uint32_t d = tid; d < nfine; d += NT) {   // the range of every bin: last t with rbin0[t] <= d
+        uint32_t lo = 0, hi = T;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (rbin0[mid] <= d) lo = mid; else hi = mid; }
+        lut[d] = (uint8_t)lo;
+    }
+    for (uint32_t t = tid; t < Ta; t += NT) {
+        const uint64_t v = vbase[h] + t;
+        const uint32_t tt = min(t, T);   // the unused segments at the end: empty
+        vrow_off[v] = (uint64_t)q0 + roff[tt];
+        vcol0[v] = (uint32_t)min((uint64_t)rbin0[tt] << sh, (uint64_t)0xffffffffu);
+        vcol1[v] = (uint32_t)min((uint64_t)rbin0[min(tt + 1, T)] << sh, (uint64_t)0xffffffffu);
+        if (t < T) cursor[t] = 0;
+    }
+    __syncthreads();
+    for (uint32_t d = tid; d < lutw * 4; d += NT) reinterpret_cast<uint8_t *>(rb)[d] = d < nfine ? lut[d] : (uint8_t)0;
+    // ---- 3. cells, a block of chunks at a time
+    const uint32_t CB = max(1u, min((uint32_t)CBL, (uint32_t)kCellsLds / T));
+    // column prefixes by (group of chunks, range): G groups of S chunks each
+    const uint32_t G = max(1u, min((uint32_t)NT / T, 16u));
+    for (uint32_t cb = 0; cb < nc; cb += CB) {
+        const uint32_t nb = min(CB, nc - cb);
+        for (uint32_t x = tid; x < nb * T; x += NT) cellm[x] = 0;
+        uint32_t E = have_E;
+        if (cb != have_cb || nb != have_nb) E = load_block(cb, nb);   // (most rows: one block, still there from the histogram)
+        else __syncthreads();
+        have_cb = cb; have_nb = nb; have_E = E;
+        for_entries(nb, E, [&](uint32_t cl, uint32_t col, bool valid) {
+            const uint32_t key = valid ? cl * 256u + (uint32_t)lut[col >> sh] : 0xffffffffu;   // (chunk, range): T <= 255
+            uint32_t runlen;
+            if (wave_run_head(key, valid, runlen)) atomicAdd(&cellm[(key >> 8) * T + (key & 255u)], runlen);
+        });
+        __syncthreads();
+        // where every range starts inside its chunk
+        for (uint32_t cl = tid; cl < nb; cl += NT) {
+            uint32_t run = 0;
+            for (uint32_t t = 0; t < T; t++) { lsm[cl * T + t] = run; run += cellm[cl * T + t]; }
+        }
+        // where every chunk's run starts inside its range: sums per group of chunks, then the walk
+        const uint32_t S = (nb + G - 1) / G;
+        const uint32_t g = tid / T, t = tid - g * T;
+        const bool on = g < G;
+        uint32_t run0 = 0;
+        if (on) {
+            uint32_t sum = 0;
+            for (uint32_t cl = g * S; cl < min(nb, (g + 1) * S); cl++) sum += cellm[cl * T + t];
+            psum[tid] = sum;
+            run0 = cursor[t];   // read before the barrier: the last group rewrites it behind it
+        }
+        __syncthreads();
+        if (on) {
+            uint32_t run = run0;
+            for (uint32_t gg = 0; gg < g; gg++) run += psum[gg * T + t];
+            const uint32_t rbase = q0 + roff[t];
+            for (uint32_t cl = g * S; cl < min(nb, (g + 1) * S); cl++) {
+                rb[lutw + (uint64_t)(cb + cl) * Ta + t] = rbase + run - lsm[cl * T + t];
+                run += cellm[cl * T + t];
+            }
+            if (g == G - 1) cursor[t] = run;   // (the last group ends at the block's end, possibly with no chunk of its own)
+        }
+        for (uint32_t cl = tid; cl < nb; cl += NT)
+            chunk_off[perm[c0 + cb + cl]] = direct_desc((uint32_t)cellbase[h], lutw + (cb + cl) * Ta, (uint32_t)sh);
+        __syncthreads();   // the block's cells and descriptors have been read
     }
 }
 }  // namespace osp

@@ -61,50 +61,93 @@ def save_tensor_as_mtx(a, save_file):
 
 
 # ---- the products -------------------------------------------------------------------------------------
-def _bias_relu_on_device(prod, bias, relu, dtype, device_index=0):
-    """``relu(prod + bias)`` for a CSR product, on the GPU: the product is scattered into a dense block in HBM, bias and
-    ReLU are applied there (a bias makes every entry of the row non-zero anyway), and what survives the ReLU comes back
-    as CSR.  ``models.py:17-31`` does the same three steps on dense tensors."""
-    dev = torch.device("cuda", device_index)
-    m, n = prod.shape
+def _coo_on_device(x, dtype, device):
+    """dense tensor / ndarray / scipy sparse -> (nrow, ncol, rows i32, cols i32, vals) torch tensors on the GPU (the file
+    order scipy's CSR gives, which is what ``save_tensor_as_mtx`` would have written)."""
+    if hasattr(x, "detach"):
+        x = x.detach().cpu().numpy()
+    if not sp.issparse(x):
+        x = sp.csr_matrix(np.asarray(x))
+    x = x.tocoo()
     tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
-    dense = torch.zeros((m, n), dtype=tdt, device=dev)
-    if prod.nnz:
-        rows = torch.from_numpy(np.repeat(np.arange(m, dtype=np.int64), np.diff(prod.indptr))).to(dev)
-        dense[rows, torch.from_numpy(prod.indices.astype(np.int64)).to(dev)] = torch.from_numpy(prod.data.astype(dtype)).to(dev)
+    return (x.shape[0], x.shape[1], torch.from_numpy(x.row.astype(np.int32)).to(device), torch.from_numpy(x.col.astype(np.int32)).to(device),
+            torch.from_numpy(x.data.astype(dtype)).to(device, tdt))
+
+
+class _DeviceLayerInput:
+    """An activation as the next product's A operand, resident on the GPU: COO arrays that either came from the host
+    once (the network's input) or ARE the previous layer's result (its colidx / vals arrays plus a row array)."""
+
+    def __init__(self, shape, rows, cols, vals, nnz, keep=()):
+        self.shape, self.rows, self.cols, self.vals, self.nnz, self.keep = shape, rows, cols, vals, nnz, keep
+
+
+def _layer_on_device(ctx, act, weight_coo, bias, relu, dtype, device):
+    """relu(act @ W.T + bias) with everything on the GPU: osp_spgemm_coo on device arrays (COO -> CSC / CSR there), then
+    osp_csr_bias_relu on the product.  Returns the CsrResult of the layer's output."""
+    M, K = act.shape
+    out_n, in_n, wr, wc, wv = weight_coo   # W is out x in; B = W^T: rows = in index, cols = out index
+    if in_n != K:
+        raise _S.OspError(1, f"inner dimensions differ: activation is {M}x{K}, weight is {out_n}x{in_n}")
+    torch.cuda.synchronize(device)   # the library works on its own stream
+    prod = ctx.spgemm_coo_device(dtype, M, K, out_n, act.nnz, (act.rows.data_ptr() if act.nnz else 0, act.cols.data_ptr() if act.nnz else 0,
+                                                              act.vals.data_ptr() if act.nnz else 0),
+                                 wv.numel(), (wc.data_ptr() if wv.numel() else 0, wr.data_ptr() if wv.numel() else 0,
+                                              wv.data_ptr() if wv.numel() else 0))
+    if bias is None and not relu:
+        return prod
+    b = None
     if bias is not None:
-        b = bias.detach() if hasattr(bias, "detach") else torch.as_tensor(np.asarray(bias))
-        dense += b.to(dev, tdt).reshape(1, -1)
-    if relu:
-        dense.clamp_(min=0)
-    nz = dense != 0
-    counts = nz.sum(dim=1)
-    indptr = np.zeros(m + 1, np.int64)
-    indptr[1:] = np.cumsum(counts.cpu().numpy())
-    cols = nz.nonzero()[:, 1]
-    return sp.csr_matrix((dense[nz].cpu().numpy(), cols.cpu().numpy(), indptr), shape=(m, n))
+        b = bias.detach().cpu().numpy() if hasattr(bias, "detach") else np.asarray(bias)
+        b = b.reshape(-1).astype(dtype)
+    out = prod.bias_relu(b, relu)
+    prod.close()
+    return out
+
+
+def _result_as_input(res, device):
+    """The previous layer's CSR result as the next product's COO operand, without leaving the GPU: its column / value
+    arrays are borrowed, the row array is written by the library (osp_result_coo_rows)."""
+    from .distributed import _as_tensor
+    _, ci, va = res.device_ptrs()
+    nnz = res.nnz
+    tdt = torch.float32 if res.dtype == np.float32 else torch.float64
+    rows = torch.empty(max(nnz, 1), dtype=torch.int32, device=device)
+    torch.cuda.synchronize(device)
+    if nnz:
+        res.coo_rows_into(rows.data_ptr())
+    cols = _as_tensor(ci, nnz, "<i4", device, torch.int32)
+    vals = _as_tensor(va, nnz, "<f4" if res.dtype == np.float32 else "<f8", device, tdt)
+    return _DeviceLayerInput(res.shape, rows, cols, vals, nnz, keep=(res,))
 
 
 def sparse_linear(act, weight, bias=None, relu=False, ctx=None, dtype=np.float32):
-    """``relu(act @ weight.T + bias)``: the product on the GPU through the SpGEMM library, bias and ReLU on the GPU as
-    well.  act: (batch x in), weight: (out x in), both dense tensors / arrays or scipy sparse; returns scipy CSR."""
-    prod = _S.spgemm(act, weight, transpose_b=True, ctx=ctx, dtype=dtype)
-    if bias is None and not relu:
-        return prod
-    return _bias_relu_on_device(prod, bias, relu, dtype, (ctx or _S.default_context()).device)
+    """``relu(act @ weight.T + bias)``: product, bias and ReLU on the GPU (osp_spgemm_coo + osp_csr_bias_relu).
+    act: (batch x in), weight: (out x in), both dense tensors / arrays or scipy sparse; returns scipy CSR."""
+    out, _ = mlp_forward(act, [(weight, bias)], ctx=ctx, dtype=dtype, relu_last=relu)
+    return out
 
 
-def mlp_forward(x, layers, ctx=None, dtype=np.float32):
+def mlp_forward(x, layers, ctx=None, dtype=np.float32, relu_last=False):
     """layers = [(W1, b1), (W2, b2), ...]; ReLU after every layer but the last (``models.py:17-31``).
-    Returns (logits CSR, [activation CSRs]) like ``MLP1.forward`` returns ``(x3, (x1, x2))``."""
-    acts = []
-    cur = x
+    Returns (logits CSR, [activation CSRs]) like ``MLP1.forward`` returns ``(x3, (x1, x2))``.
+    The activations never leave the GPU between layers: a layer's result (CSR in HBM) is the next product's operand as it
+    stands; only what is returned is copied to the host, at the end."""
+    ctx = ctx or _S.default_context()
+    device = torch.device("cuda", ctx.device)
+    M, K, r, c, v = _coo_on_device(x, dtype, device)
+    cur = _DeviceLayerInput((M, K), r, c, v, v.numel())
+    results = []
     for li, (w, b) in enumerate(layers):
         last = li == len(layers) - 1
-        cur = sparse_linear(cur, w, b, relu=not last, ctx=ctx, dtype=dtype)
+        res = _layer_on_device(ctx, cur, _coo_on_device(w, dtype, device), b, relu_last if last else True, dtype, device)
+        results.append(res)
         if not last:
-            acts.append(cur)
-    return cur, acts
+            cur = _result_as_input(res, device)
+    outs = [r_.to_scipy() for r_ in results]
+    for r_ in results:
+        r_.close()
+    return outs[-1], outs[:-1]
 
 
 def mlp_forward_from_mtx(directory, nlayers=3, ctx=None, dtype=np.float32):

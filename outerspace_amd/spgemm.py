@@ -68,6 +68,21 @@ class CsrResult:
         _lib.check(_lib.lib().osp_result_device_ptrs(self._h, C.byref(r), C.byref(c), C.byref(v)))
         return r.value or 0, c.value or 0, v.value or 0
 
+    def bias_relu(self, bias=None, relu=True):
+        """``relu(C + bias)`` with the zeros dropped, as a new CSR result on the device (``osp_csr_bias_relu``): what
+        ``models.py:17-31`` does between two layers.  bias: N values (numpy, C's dtype) or None."""
+        b = None if bias is None else np.ascontiguousarray(bias, self.dtype)
+        if b is not None and b.shape != (self.shape[1],):
+            raise ValueError(f"bias must have {self.shape[1]} entries")
+        h = C.c_void_p()
+        _lib.check(_lib.lib().osp_csr_bias_relu(self._h, _ptr(b) if b is not None else None, _lib.OSP_HOST, int(bool(relu)), C.byref(h)))
+        return CsrResult(self._ctx, h)
+
+    def coo_rows_into(self, rows_device_ptr):
+        """Row index of every entry into caller-owned DEVICE memory (nnz u32 values): with ``device_ptrs()[1:]`` the COO
+        form ``Context.spgemm_coo_device`` takes (``osp_result_coo_rows``)."""
+        _lib.check(_lib.lib().osp_result_coo_rows(self._h, C.c_void_p(int(rows_device_ptr))))
+
     def to_scipy(self):
         import scipy.sparse as sp
         rowptr, colidx, vals = self.to_host()
@@ -209,6 +224,15 @@ class Context:
                                              C.byref(cfg), C.byref(h)))
         return CsrResult(self, h)
 
+    def spgemm_coo_device(self, dtype, M, K, N, nnz_a, a_ptrs, nnz_b, b_ptrs, *, partial_capacity=0):
+        """``spgemm_coo`` on DEVICE arrays: a_ptrs / b_ptrs = (rows, cols, vals) addresses (u32, u32, dtype), entries in any
+        order.  ``result.info['ms_ingest']`` is the device time of the two COO -> CSC / CSR conversions."""
+        cfg = self._config(True, partial_capacity, None)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().osp_spgemm_coo(self._h, _DT[np.dtype(dtype)], M, K, N, int(nnz_a), *[C.c_void_p(int(p)) for p in a_ptrs],
+                                             int(nnz_b), *[C.c_void_p(int(p)) for p in b_ptrs], _lib.OSP_DEVICE, C.byref(cfg), C.byref(h)))
+        return CsrResult(self, h)
+
     def spgemm_csc_csr_device(self, dtype, M, K, N, ptrs, *, validate=False, partial_capacity=0, k_range=None, row_shard=None):
         """Same with six DEVICE addresses (ints): a_colptr, a_rowidx, a_vals, b_rowptr, b_colidx, b_vals.
         The arrays must be COMPLETE when this is called: the context works on a stream of its own (or the one it was
@@ -230,13 +254,14 @@ class Context:
                                                   _lib.OSP_DEVICE, C.byref(cfg), C.byref(h)))
         return CsrResult(self, h)
 
-    def merge_record_parts_device(self, dtype, M, N, part_ptrs, *, partial_capacity=0):
-        """Sum parts given as (rowptr, records) DEVICE addresses (``osp_merge_record_parts``) into one CSR."""
+    def merge_record_parts_device(self, dtype, M, N, part_ptrs, *, partial_capacity=0, validate=False):
+        """Sum parts given as (rowptr, records) DEVICE addresses (``osp_merge_record_parts``) into one CSR.
+        validate=True checks the offsets and the columns on the device first."""
         n = len(part_ptrs)
         rp, rc = (C.c_void_p * n)(), (C.c_void_p * n)()
         for i, (r, c) in enumerate(part_ptrs):
             rp[i], rc[i] = int(r), int(c)
-        cfg = self._config(False, partial_capacity, None)
+        cfg = self._config(validate, partial_capacity, None)
         h = C.c_void_p()
         _lib.check(_lib.lib().osp_merge_record_parts(self._h, _DT[np.dtype(dtype)], M, N, n, rp, rc, _lib.OSP_DEVICE, C.byref(cfg),
                                                      C.byref(h)))

@@ -70,13 +70,23 @@ def _ctx_shared():
     c.close()
 
 
-@pytest.fixture(params=["outer", "rowwise"])
+@pytest.fixture(params=["outer", "rowwise", "outer-split"])
 def ctx(request, _ctx_shared):
     """Every test that multiplies runs once per formulation (osp_config_t.algorithm): outer product with staging, and the
-    row-wise variant that forms short rows inside the merge kernel.  Both must equal the oracle bit for bit.
+    row-wise variant that forms short rows inside the merge kernel -- both with long rows written straight into their
+    column ranges by the multiply phase ("direct" rows, the default) -- and the outer product with every long row split
+    after the multiply instead (OSP_DIRECT=0).  All must equal the oracle bit for bit.
 
     ONE library context (device 0: stream + buffer pool) for the whole session: a process normally keeps one, and a
     context per test module only meant freeing every pooled device buffer and allocating it again a moment later."""
-    _ctx_shared.algorithm = request.param
+    _ctx_shared.algorithm = "outer" if request.param == "outer-split" else request.param
+    had = os.environ.get("OSP_DIRECT")
+    if request.param == "outer-split":
+        os.environ["OSP_DIRECT"] = "0"
     yield _ctx_shared
     _ctx_shared.algorithm = "outer"
+    if request.param == "outer-split":
+        if had is None:
+            os.environ.pop("OSP_DIRECT", None)
+        else:
+            os.environ["OSP_DIRECT"] = had

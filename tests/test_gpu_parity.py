@@ -967,3 +967,80 @@ def test_hub_segments_dense_accumulation(ctx, port, monkeypatch, dt):
     n, rows, cols_, vals = gen.rmat_coo(14, 16, "g500", seed=2, dtype=dt)
     got, want = run_both(ctx, port, n, n, n, (rows, cols_, vals), (rows, cols_, vals), dt)
     assert_same(got, want)
+
+
+@pytest.mark.parametrize("direct_max", [None, "0", "5000", "40000"])
+def test_direct_rows_written_by_the_multiply(port, monkeypatch, _ctx_shared, direct_max):
+    """Long rows that one workgroup could split are written straight into their column ranges by the multiply phase
+    (osp_split.h, direct_plan_kernel): no split pass over their records.  OSP_DIRECT_MAX bounds the rows it applies to, so
+    direct rows, split rows and stretch-split rows meet in one product; the panel variant cuts the product into several
+    row panels (every panel plans its own direct rows).  Same bits as the oracle every way."""
+    if direct_max is not None:
+        monkeypatch.setenv("OSP_DIRECT_MAX", direct_max)
+    monkeypatch.setenv("OSP_SPLIT_ROW_MAX", "60000")     # rows beyond: the stretch split
+    ctx = _ctx_shared
+    for dt, preset, scale in ((np.float64, "mild", 15), (np.float32, "g500", 13)):
+        n, rows, cols, vals = gen.rmat_coo(scale, 16, preset, seed=4, dtype=dt)
+        for cap in (0, 1 << 21):
+            got, want = run_both(ctx, port, n, n, n, (rows, cols, vals), (rows, cols, vals), dt, partial_capacity=cap)
+            assert got.info["heavy_rows"] > 50
+            if direct_max == "0":
+                assert got.info["direct_rows"] == 0 and got.info["split_launches"] >= 1
+            else:
+                assert got.info["direct_rows"] > 0 and got.info["direct_partials"] > 0 and got.info["direct_plan_launches"] >= 1
+                assert got.info["direct_rows"] <= got.info["heavy_rows"]
+            if cap:
+                assert got.info["panels"] > 1
+            assert_same(got, want)
+            got.close()
+
+
+def test_record_parts_are_validated(_ctx_shared):
+    """osp_merge_record_parts with cfg.validate: a column beyond N or a broken offset array is an error code, not an
+    out-of-bounds access on the device."""
+    import torch
+    from outerspace_amd import _lib
+    from outerspace_amd import spgemm as S
+    ctx = _ctx_shared
+    dev = torch.device("cuda", 0)
+    M, N = 4, 10
+    rec = np.zeros(6, dtype=S.aos_dtype(np.float64))
+    rec["idx"] = [1, 3, 9, 0, 2, 7]
+    rec["val"] = np.arange(6) + 1.0
+    rp = np.array([0, 2, 3, 3, 6], np.int64)
+
+    def run(rp_h, rec_h, validate):
+        t_rp = torch.from_numpy(rp_h).to(dev)
+        t_rec = torch.from_numpy(rec_h.view(np.uint8)).to(dev)
+        torch.cuda.synchronize()
+        return ctx.merge_record_parts_device(np.float64, M, N, [(t_rp.data_ptr(), t_rec.data_ptr())], validate=validate)
+
+    ok = run(rp, rec, True)
+    assert ok.nnz == 6 and np.array_equal(ok.colidx, [1, 3, 9, 0, 2, 7])
+    ok.close()
+    bad = rec.copy()
+    bad["idx"][2] = 10
+    with pytest.raises(S.OspError) as ei:
+        run(rp, bad, True)
+    assert ei.value.status == _lib.ERR_RANGE
+    with pytest.raises(S.OspError) as ei:
+        run(np.array([0, 3, 2, 3, 6], np.int64), rec, True)
+    assert ei.value.status == _lib.ERR_ARG
+
+
+def test_two_devices_one_thread():
+    """Contexts on two devices owned by one thread: the pinned staging object (and its events) is per device (ADVICE
+    round 2: one thread-local object recorded device-0 events on a device-1 stream).  Needs two GPUs; the builder's box
+    has one, the driver's 8-GPU node runs it."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    from outerspace_amd import spgemm as S
+    n, rows, cols, vals = gen.rmat_coo(9, 8, "mild", seed=3)
+    acsc, bcsr = S.coo_to_csc(n, rows, cols, vals), S.coo_to_csr(n, rows, cols, vals)
+    with S.Context(0) as c0, S.Context(1) as c1:
+        r0 = c0.spgemm_csc_csr(n, n, n, *acsc, *bcsr)
+        r1 = c1.spgemm_csc_csr(n, n, n, *acsc, *bcsr)
+        r0b = c0.spgemm_csc_csr(n, n, n, *acsc, *bcsr)
+        for r in (r1, r0b):
+            assert np.array_equal(r.rowptr, r0.rowptr) and np.array_equal(r.colidx, r0.colidx) and np.array_equal(r.vals, r0.vals)

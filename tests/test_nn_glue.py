@@ -67,3 +67,43 @@ def test_sparse_mlp_chain_f32(golden_dir, tmp_path):
     chain = su.weight_chain([w for w, _ in layers])
     dense = layers[2][0] @ layers[1][0] @ layers[0][0]
     assert np.allclose(chain.toarray(), dense.numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_bias_relu_epilogue_on_device(dt):
+    """osp_csr_bias_relu against the dense definition (models.py:17-31: x = relu(fc(x)), the bias added to EVERY element):
+    with and without bias, with and without ReLU; zeros are dropped, an entry that the bias lifts above zero appears,
+    rows may end up empty; values bit-equal to the same arithmetic in numpy."""
+    import scipy.sparse as sp
+    from outerspace_amd import spgemm as S
+    rng = np.random.default_rng(7)
+    M, K, N = 37, 50, 130
+    A = sp.random(M, K, 0.15, random_state=1, dtype=np.float64).astype(dt).tocsr()
+    B = sp.random(K, N, 0.1, random_state=2, dtype=np.float64).astype(dt).tocsr()
+    A.data -= dt(0.5)   # negative products too
+    A[5, :] = 0          # an empty product row
+    A.eliminate_zeros()
+    bias = rng.standard_normal(N).astype(dt) * dt(0.1)
+    bias[::7] = 0
+    ctx = S.default_context()
+    a, b = A.tocoo(), B.tocoo()
+    res = ctx.spgemm_coo(M, K, N, (a.row, a.col, a.data), (b.row, b.col, b.data))
+    C = res.to_scipy().toarray()
+    for use_bias in (True, False):
+        for relu in (True, False):
+            out = res.bias_relu(bias if use_bias else None, relu)
+            got = out.to_scipy()
+            want = C + bias[None, :] if use_bias else C.copy()
+            if not use_bias:
+                want = np.where(res.to_scipy().toarray() != 0, want, 0)   # only stored entries take part
+            if relu:
+                want = np.maximum(want, 0)
+            assert out.nnz == np.count_nonzero(want)
+            assert np.array_equal(got.toarray(), want)
+            assert np.all(np.diff(got.indptr) >= 0) and got.indptr[-1] == out.nnz
+            for r in range(M):
+                cols = got.indices[got.indptr[r]:got.indptr[r + 1]]
+                assert np.all(np.diff(cols) > 0)
+            out.close()
+    res.close()

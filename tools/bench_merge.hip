@@ -139,7 +139,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&g_stage, P * sizeof(Part<double>)));
     pack_kernel<<<(unsigned)((P + 255) / 256), 256>>>(pcol, pval, P, g_stage);
     CK(hipMalloc(&g_desc, (uint64_t)ntiles * sizeof(TileDesc)));
-    tile_desc_kernel<1 << 20><<<(ntiles + 255) / 256, 256>>>(tile_rows, ntiles, M, row_off, 0, 0u, nullptr, nullptr, 0u, nullptr, 22, nullptr, nullptr, g_desc);
+    tile_desc_kernel<1 << 20><<<(ntiles + 255) / 256, 256>>>(tile_rows, ntiles, M, row_off, 0, 0u, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, g_desc);
     if (l1bits) desc_l1_kernel<<<(ntiles + 255) / 256, 256>>>(g_desc, ntiles, l1bits);
     if (getenv("GRID")) g_grid = atoi(getenv("GRID"));
     CK(hipDeviceSynchronize());
