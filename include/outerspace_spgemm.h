@@ -233,6 +233,61 @@ int osp_merge_record_parts(osp_context_t ctx, osp_dtype_t dtype, uint64_t M, uin
                            const int64_t *const *rowptrs, const void *const *records, osp_memspace_t space,
                            const osp_config_t *cfg, osp_result_t *result);
 
+/* ---- several GPUs of one node: the k-sharded product (SURVEY.md 8e / 8b "optional device ordinal list") ------------- */
+/*
+ * No reference counterpart (the reference is one process, one thread).  k is cut into one slab per rank, balanced by
+ * partial products; rank g holds only columns [k_g, k_g+1) of A and rows [k_g, k_g+1) of B and multiplies them; the
+ * partial products travel ONCE, unmerged, to the rank that owns their output row (direct GPU-to-GPU copies, pipelined
+ * behind the multiply panel by panel), and every rank merges its row range as the pieces arrive -- parts in rank order =
+ * ascending k, the single-GPU summation order: the result is bit-identical to osp_spgemm_csc_csr.  The result stays
+ * row-sharded (shard g on device g); osp_multi_result_copy_csr gathers it to the host.
+ * devices[] may name an ordinal more than once: logical ranks that share a GPU (how the tests run on a one-GPU box).
+ * The calling thread drives rank 0 and starts one host thread per further rank for the duration of a product.
+ */
+#define OSP_MULTI_MAX_RANKS 16
+typedef struct osp_multi_context_s *osp_multi_context_t;
+typedef struct osp_multi_operands_s *osp_multi_operands_t;
+typedef struct osp_multi_result_s *osp_multi_result_t;
+typedef struct osp_multi_rank_info {
+    int device;
+    uint64_t k_begin, k_end;        /* the rank's slab of the shared dimension */
+    uint64_t row_begin, row_end;    /* the output rows it owns */
+    uint64_t partials_local;        /* partial products it formed */
+    uint64_t records_received;      /* partial products it merged (its own included) */
+    uint64_t bytes_sent;            /* records copied to OTHER ranks */
+    uint64_t nnz_c;                 /* entries of its shard */
+    float ms_symbolic, ms_multiply_kernel, ms_merge, ms_total;   /* host clock of the rank's thread; kernel time from HIP events */
+} osp_multi_rank_info_t;
+typedef struct osp_multi_info {
+    int nranks, subpanels;          /* sub-panels per row range: the granularity of the multiply / copy / merge pipeline */
+    uint64_t M, K, N, nnz_c, partials, bytes_exchanged;
+    float ms_total;                 /* wall time of the product (operands resident on their ranks) */
+    float ms_upload;                /* host -> devices distribution of the slabs (osp_multi_operands_create) */
+    osp_multi_rank_info_t rank[OSP_MULTI_MAX_RANKS];
+} osp_multi_info_t;
+int osp_multi_context_create(const int *devices, int ndev, osp_multi_context_t *mc);
+int osp_multi_context_destroy(osp_multi_context_t mc);
+/* Cut k into slabs and put every rank's slab on its GPU (HOST operands, the six arrays of osp_spgemm_csc_csr). */
+int osp_multi_operands_create(osp_multi_context_t mc, osp_dtype_t dtype, uint64_t M, uint64_t K, uint64_t N,
+                              const int64_t *a_colptr, const uint32_t *a_rowidx, const void *a_vals,
+                              const int64_t *b_rowptr, const uint32_t *b_colidx, const void *b_vals,
+                              osp_multi_operands_t *ops);
+int osp_multi_operands_destroy(osp_multi_operands_t ops);
+/* The product of resident slabs (repeatable).  cfg: validate and partial_capacity are honoured. */
+int osp_spgemm_multi(osp_multi_context_t mc, osp_multi_operands_t ops, const osp_config_t *cfg, osp_multi_result_t *result);
+/* All of it in one call -- what a caller of cscMulcsr(csc, csr) (SimSpGEMM.cpp:265) with several GPUs writes.  The context
+ * comes back because the result's shards live in its pools: destroy the result first, then the context. */
+int osp_spgemm_csc_csr_multi(const int *devices, int ndev, osp_dtype_t dtype, uint64_t M, uint64_t K, uint64_t N,
+                             const int64_t *a_colptr, const uint32_t *a_rowidx, const void *a_vals,
+                             const int64_t *b_rowptr, const uint32_t *b_colidx, const void *b_vals,
+                             const osp_config_t *cfg, osp_multi_context_t *mc, osp_multi_result_t *result);
+int osp_multi_result_info(osp_multi_result_t r, osp_multi_info_t *info);
+/* Shard `rank` (borrowed handle, valid until osp_multi_result_destroy): rows [row_begin, row_end), rowptr local to it. */
+int osp_multi_result_shard(osp_multi_result_t r, int rank, uint64_t *row_begin, uint64_t *row_end, osp_result_t *shard);
+/* The whole CSR on the host: rowptr[M+1], colidx[nnz_c], vals[nnz_c]; any pointer may be NULL. */
+int osp_multi_result_copy_csr(osp_multi_result_t r, int64_t *rowptr, uint32_t *colidx, void *vals);
+int osp_multi_result_destroy(osp_multi_result_t r);
+
 /* ---- between the layers of a sparse MLP --------------------------------- */
 /*
  * out = relu(C + bias) with the zeros dropped, as a new CSR result on the same context: what NN_models/models.py:17-31

@@ -61,6 +61,27 @@ class Panel(C.Structure):
 
 PANEL_FN = C.CFUNCTYPE(C.c_int, C.POINTER(Panel), C.c_void_p)
 
+MULTI_MAX_RANKS = 16
+
+
+class MultiRankInfo(C.Structure):
+    """osp_multi_rank_info_t"""
+    _fields_ = [("device", C.c_int), ("k_begin", C.c_uint64), ("k_end", C.c_uint64), ("row_begin", C.c_uint64), ("row_end", C.c_uint64),
+                ("partials_local", C.c_uint64), ("records_received", C.c_uint64), ("bytes_sent", C.c_uint64), ("nnz_c", C.c_uint64),
+                ("ms_symbolic", C.c_float), ("ms_multiply_kernel", C.c_float), ("ms_merge", C.c_float), ("ms_total", C.c_float)]
+
+
+class MultiInfo(C.Structure):
+    """osp_multi_info_t"""
+    _fields_ = [("nranks", C.c_int), ("subpanels", C.c_int), ("M", C.c_uint64), ("K", C.c_uint64), ("N", C.c_uint64),
+                ("nnz_c", C.c_uint64), ("partials", C.c_uint64), ("bytes_exchanged", C.c_uint64), ("ms_total", C.c_float),
+                ("ms_upload", C.c_float), ("rank", MultiRankInfo * MULTI_MAX_RANKS)]
+
+    def as_dict(self):
+        d = {name: getattr(self, name) for name, _ in self._fields_ if name != "rank"}
+        d["ranks"] = [{n: getattr(self.rank[g], n) for n, _ in MultiRankInfo._fields_} for g in range(self.nranks)]
+        return d
+
 
 # every symbol include/outerspace_spgemm.h declares
 EXPORTS = [
@@ -71,6 +92,8 @@ EXPORTS = [
     "osp_merge_csr_parts", "osp_result_info", "osp_result_copy_csr", "osp_result_device_ptrs",
     "osp_result_destroy", "osp_mtx_read", "osp_host_free", "osp_coo_to_compressed_f32",
     "osp_coo_to_compressed_f64", "osp_spgemm_mtx", "osp_result_write_mtx", "osp_csr_bias_relu", "osp_result_coo_rows",
+    "osp_multi_context_create", "osp_multi_context_destroy", "osp_multi_operands_create", "osp_multi_operands_destroy", "osp_spgemm_multi",
+    "osp_spgemm_csc_csr_multi", "osp_multi_result_info", "osp_multi_result_shard", "osp_multi_result_copy_csr", "osp_multi_result_destroy",
 ]
 
 _lib = None
@@ -129,6 +152,17 @@ def lib():
         getattr(L, f"osp_coo_to_compressed_{sfx}").argtypes = [i32, u64, u64, vp, vp, vp, vp, vp, vp]
     L.osp_spgemm_mtx.argtypes = [vp, i32, C.c_char_p, C.c_char_p, i32, C.POINTER(Config), C.POINTER(vp)]
     L.osp_result_write_mtx.argtypes = [vp, C.c_char_p]
+    L.osp_multi_context_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
+    L.osp_multi_context_destroy.argtypes = [vp]
+    L.osp_multi_operands_create.argtypes = [vp, i32, u64, u64, u64, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
+    L.osp_multi_operands_destroy.argtypes = [vp]
+    L.osp_spgemm_multi.argtypes = [vp, vp, C.POINTER(Config), C.POINTER(vp)]
+    L.osp_spgemm_csc_csr_multi.argtypes = [C.POINTER(i32), i32, i32, u64, u64, u64, vp, vp, vp, vp, vp, vp, C.POINTER(Config), C.POINTER(vp),
+                                           C.POINTER(vp)]
+    L.osp_multi_result_info.argtypes = [vp, C.POINTER(MultiInfo)]
+    L.osp_multi_result_shard.argtypes = [vp, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(vp)]
+    L.osp_multi_result_copy_csr.argtypes = [vp, vp, vp, vp]
+    L.osp_multi_result_destroy.argtypes = [vp]
     L.osp_csr_bias_relu.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
     L.osp_result_coo_rows.argtypes = [vp, vp]
     _lib = L

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -836,7 +837,9 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
                            const uint64_t *d_row_off,
                            uint64_t P, uint64_t cap_cfg, PhaseTimer &tm, uint64_t r_lo = 0, uint64_t r_hi = ~0ull,
                            uint64_t off_lo = 0, const PanelSink *sink = nullptr, const ChunkTable<T> *ct = nullptr,
-                           const DirectSrc *ds = nullptr) {
+                           const DirectSrc *ds = nullptr, const std::vector<uint64_t> *cuts = nullptr) {
+    // cuts (optional, ascending row ids inside (r_lo, r_hi)): a panel never reaches across one of them -- the multi-GPU
+    // merge makes its panels end where the pieces it receives end (osp_multi.h)
     // output rows [r_lo, r_hi) only (row-sharded multi-GPU mode); P = their partial products, off_lo = row_off[r_lo]
     if (r_hi == ~0ull) r_hi = M_all;
     const uint64_t M = r_hi - r_lo;
@@ -899,12 +902,13 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
                 free_b / 1e9, (unsigned long long)cap, cap * E / 1e9);
     std::vector<uint64_t> bounds{r_lo};  // absolute row ids
     std::vector<uint64_t> h_off_v;         // row_off[r_lo .. r_hi] on the host (multi-panel only)
-    if (P <= cap) {
+    if (P <= cap && !(cuts && !cuts->empty())) {
         bounds.push_back(r_hi);
     } else {
         h_off_v.resize(M + 1);
         copy_d2h(h_off_v.data(), d_row_off + r_lo, (M + 1) * sizeof(uint64_t), s);
         uint64_t r = 0;
+        size_t ci = 0;
         while (r < M) {
             // largest r1 with row_off[r1] - row_off[r] <= cap
             uint64_t r1 = std::upper_bound(h_off_v.begin() + r, h_off_v.end(), h_off_v[r] + cap) - h_off_v.begin() - 1;
@@ -913,6 +917,10 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
                             std::to_string(h_off_v[r + 1] - h_off_v[r]) + " partial products, staging capacity is " +
                             std::to_string(cap));
             r1 = std::min(r1, M);
+            if (cuts) {
+                while (ci < cuts->size() && (*cuts)[ci] <= r_lo + r) ci++;
+                if (ci < cuts->size() && (*cuts)[ci] < r_lo + r1) r1 = (*cuts)[ci] - r_lo;
+            }
             bounds.push_back(r_lo + r1);
             r = r1;
         }
@@ -1053,7 +1061,9 @@ template <class T> struct RecordPartsProducer : Producer<T> {
     const int64_t *const *d_rowptrs; const Part<T> *const *d_recs;
     int nparts;
     const uint64_t *row_off;
+    const std::function<void(uint64_t, uint64_t)> *before = nullptr;   // called with the panel's rows before its records are read
     void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &, const uint32_t *, Part<T> *) override {
+        if (before) (*before)(r0, r1);
         const uint64_t nr = r1 - r0;
         parts_scatter_rec_kernel<T><<<grid_for(nr * kWave, 256), 256, 0, ctx->stream>>>(d_rowptrs, d_recs, nparts, r0, r1, row_off, base, stage);
     }
@@ -1448,7 +1458,9 @@ static void merge_parts_impl(Context *ctx, Result *res, uint64_t M, uint64_t N, 
 
 template <class T>
 static void merge_record_parts_impl(Context *ctx, Result *res, uint64_t M, uint64_t N, int nparts, const int64_t *const *rowptrs,
-                                    const void *const *records, osp_memspace_t space, const osp_config_t &cfg) {
+                                    const void *const *records, osp_memspace_t space, const osp_config_t &cfg,
+                                    const std::vector<uint64_t> *cuts = nullptr,
+                                    const std::function<void(uint64_t, uint64_t)> *before = nullptr) {
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
     PhaseTimer tm(s);
@@ -1491,8 +1503,8 @@ static void merge_record_parts_impl(Context *ctx, Result *res, uint64_t M, uint6
     tm.end(PH_SYM);
     res->info.partials = P;
     RecordPartsProducer<T> prod;
-    prod.ctx = ctx; prod.d_rowptrs = d_rp; prod.d_recs = d_rc; prod.nparts = nparts; prod.row_off = row_off;
-    merge_pipeline<T>(ctx, res, prod, M, N, row_off, P, cfg.partial_capacity, tm);
+    prod.ctx = ctx; prod.d_rowptrs = d_rp; prod.d_recs = d_rc; prod.nparts = nparts; prod.row_off = row_off; prod.before = before;
+    merge_pipeline<T>(ctx, res, prod, M, N, row_off, P, cfg.partial_capacity, tm, 0, ~0ull, 0, nullptr, nullptr, nullptr, cuts);
     OSP_HIP(hipEventRecord(ev.b, s));
     OSP_HIP(hipStreamSynchronize(s));
     res->info.ms_total = ev.ms();
@@ -1550,6 +1562,8 @@ static void destroy_result(Result *r) {
 }
 
 }  // namespace osp
+
+#include "osp_multi.h"
 
 using namespace osp;
 
@@ -1982,6 +1996,174 @@ int osp_result_coo_rows(osp_result_t r_, uint32_t *rows_device) {
     OSP_HIP(hipGetLastError());
     return OSP_OK;
     OSP_GUARD_END
+}
+
+// ---- several GPUs of one node (osp_multi.h) ----
+int osp_multi_context_create(const int *devices, int ndev, osp_multi_context_t *out) {
+    if (!devices || !out) return fail(OSP_ERR_ARG, "null argument");
+    if (ndev < 1 || ndev > OSP_MULTI_MAX_RANKS) return fail(OSP_ERR_ARG, "between 1 and %d ranks", OSP_MULTI_MAX_RANKS);
+    MultiContext *mc = new MultiContext;
+    try {
+        for (int g = 0; g < ndev; g++) {
+            osp_context_t c = nullptr;
+            const int st = osp_context_create(devices[g], &c);
+            if (st) { delete mc; return st; }   // (the message is already set)
+            mc->devices.push_back(devices[g]);
+            mc->ctx.push_back((Context *)c);
+            hipStream_t cs = nullptr;
+            OSP_HIP(hipSetDevice(devices[g]));
+            OSP_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            mc->copy.push_back(cs);
+        }
+        // direct copies between the GPUs where the hardware allows them (xGMI); without peer access a copy is staged
+        // through the host by the runtime, which is slower but correct
+        for (int g = 0; g < ndev; g++)
+            for (int h = 0; h < ndev; h++) {
+                if (devices[g] == devices[h]) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devices[g], devices[h]) == hipSuccess && can) {
+                    (void)hipSetDevice(devices[g]);
+                    (void)hipDeviceEnablePeerAccess(devices[h], 0);
+                    (void)hipGetLastError();   // "already enabled" is fine
+                }
+            }
+    } catch (const Error &e) {
+        delete mc;
+        return fail(e.status, "%s", e.what());
+    }
+    *out = (osp_multi_context_t)mc;
+    return OSP_OK;
+}
+int osp_multi_context_destroy(osp_multi_context_t mc) {
+    delete (MultiContext *)mc;
+    return OSP_OK;
+}
+
+int osp_multi_operands_create(osp_multi_context_t mc_, osp_dtype_t dtype, uint64_t M, uint64_t K, uint64_t N, const int64_t *a_colptr,
+                              const uint32_t *a_rowidx, const void *a_vals, const int64_t *b_rowptr, const uint32_t *b_colidx,
+                              const void *b_vals, osp_multi_operands_t *out) {
+    MultiContext *mc = (MultiContext *)mc_;
+    if (!mc || !out || !a_colptr || !b_rowptr) return fail(OSP_ERR_ARG, "null argument");
+    if (dtype != OSP_F32 && dtype != OSP_F64) return fail(OSP_ERR_ARG, "dtype must be OSP_F32 or OSP_F64");
+    if (M >= 0xffffffffull || N > 0xffffffffull || K >= 0xffffffffull) return fail(OSP_ERR_ARG, "dimension exceeds the u32 index type");
+    const int64_t nnz_a = a_colptr[K], nnz_b = b_rowptr[K];
+    if (nnz_a < 0 || nnz_b < 0 || (uint64_t)nnz_a >= 0xffffffffull || (uint64_t)nnz_b >= 0xffffffffull)
+        return fail(OSP_ERR_ARG, "operands with >= 2^32 non-zeros are not supported");
+    if ((nnz_a && (!a_rowidx || !a_vals)) || (nnz_b && (!b_colidx || !b_vals))) return fail(OSP_ERR_ARG, "null operand array");
+    for (uint64_t k = 0; k < K; k++)
+        if (a_colptr[k + 1] < a_colptr[k] || b_rowptr[k + 1] < b_rowptr[k] || a_colptr[0] != 0 || b_rowptr[0] != 0)
+            return fail(OSP_ERR_ARG, "pointer array is not a monotone 0..nnz sequence");
+    MultiOperands *ops = new MultiOperands;
+    ops->mc = mc; ops->dtype = dtype; ops->M = M; ops->K = K; ops->N = N;
+    try {
+        if (dtype == OSP_F32) multi_upload<float>(mc, ops, a_colptr, a_rowidx, (const float *)a_vals, b_rowptr, b_colidx, (const float *)b_vals);
+        else multi_upload<double>(mc, ops, a_colptr, a_rowidx, (const double *)a_vals, b_rowptr, b_colidx, (const double *)b_vals);
+    } catch (const Error &e) {
+        delete ops;
+        return fail(e.status, "%s", e.what());
+    } catch (const std::exception &e) {
+        delete ops;
+        return fail(OSP_ERR_ALLOC, "%s", e.what());
+    }
+    *out = (osp_multi_operands_t)ops;
+    return OSP_OK;
+}
+int osp_multi_operands_destroy(osp_multi_operands_t ops) {
+    delete (MultiOperands *)ops;
+    return OSP_OK;
+}
+
+int osp_spgemm_multi(osp_multi_context_t mc_, osp_multi_operands_t ops_, const osp_config_t *cfg_, osp_multi_result_t *out) {
+    MultiContext *mc = (MultiContext *)mc_;
+    MultiOperands *ops = (MultiOperands *)ops_;
+    if (!mc || !ops || !out) return fail(OSP_ERR_ARG, "null argument");
+    if (ops->mc != mc) return fail(OSP_ERR_ARG, "operands belong to another multi-GPU context");
+    osp_config_t cfg;
+    if (cfg_) cfg = *cfg_; else osp_config_default(&cfg);
+    MultiResult *res = new MultiResult;
+    res->mc = mc;
+    res->dtype = ops->dtype;
+    try {
+        if (cfg.validate) {
+            // per slab, as the single-GPU entry point does: ordering, ranges, duplicates (233)
+            for (size_t g = 0; g < mc->ctx.size(); g++) {
+                Context *c = mc->ctx[g];
+                OSP_HIP(hipSetDevice(c->device));
+                const MultiOperands::Slab &sl = ops->slab[g];
+                Scratch sc(c);
+                uint32_t *flags = sc.get<uint32_t>(2);
+                OSP_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(uint32_t), c->stream));
+                if (sl.nnz_a) validate_idx_kernel<<<grid_for(sl.nnz_a, 256), 256, 0, c->stream>>>(sl.a_colptr, sl.a_rowidx, sl.K, sl.nnz_a, ops->M, flags);
+                if (sl.nnz_b) validate_idx_kernel<<<grid_for(sl.nnz_b, 256), 256, 0, c->stream>>>(sl.b_rowptr, sl.b_colidx, sl.K, sl.nnz_b, ops->N, flags + 1);
+                uint32_t fa = 0, fb = 0;
+                { Gather gt(c->stream); gt.add(&fa, (const uint32_t *)flags); gt.add(&fb, (const uint32_t *)flags + 1); gt.wait(); }
+                check_flags(fa, "A (CSC)");
+                check_flags(fb, "B (CSR)");
+            }
+        }
+        if (ops->dtype == OSP_F32) multi_product<float>(mc, ops, res, cfg);
+        else multi_product<double>(mc, ops, res, cfg);
+        res->info.ms_upload = ops->ms_upload;
+    } catch (const Error &e) {
+        delete res;
+        return fail(e.status, "%s", e.what());
+    } catch (const std::exception &e) {
+        delete res;
+        return fail(OSP_ERR_ALLOC, "%s", e.what());
+    }
+    *out = (osp_multi_result_t)res;
+    return OSP_OK;
+}
+
+int osp_spgemm_csc_csr_multi(const int *devices, int ndev, osp_dtype_t dtype, uint64_t M, uint64_t K, uint64_t N, const int64_t *a_colptr,
+                             const uint32_t *a_rowidx, const void *a_vals, const int64_t *b_rowptr, const uint32_t *b_colidx,
+                             const void *b_vals, const osp_config_t *cfg, osp_multi_context_t *mc_out, osp_multi_result_t *out) {
+    if (!mc_out || !out) return fail(OSP_ERR_ARG, "null argument");
+    osp_multi_context_t mc = nullptr;
+    osp_multi_operands_t ops = nullptr;
+    int st = osp_multi_context_create(devices, ndev, &mc);
+    if (st) return st;
+    st = osp_multi_operands_create(mc, dtype, M, K, N, a_colptr, a_rowidx, a_vals, b_rowptr, b_colidx, b_vals, &ops);
+    if (st == OSP_OK) st = osp_spgemm_multi(mc, ops, cfg, out);
+    if (ops) osp_multi_operands_destroy(ops);   // the result does not refer to the operands
+    if (st) { osp_multi_context_destroy(mc); return st; }
+    *mc_out = mc;   // the result's shards live in this context's pools: destroy the result first, then the context
+    return OSP_OK;
+}
+
+int osp_multi_result_info(osp_multi_result_t r_, osp_multi_info_t *info) {
+    MultiResult *r = (MultiResult *)r_;
+    if (!r || !info) return fail(OSP_ERR_ARG, "null argument");
+    *info = r->info;
+    return OSP_OK;
+}
+int osp_multi_result_shard(osp_multi_result_t r_, int rank, uint64_t *row_begin, uint64_t *row_end, osp_result_t *shard) {
+    MultiResult *r = (MultiResult *)r_;
+    if (!r || rank < 0 || rank >= (int)r->shard.size()) return fail(OSP_ERR_ARG, "bad result or rank");
+    if (row_begin) *row_begin = r->row_bounds[rank];
+    if (row_end) *row_end = r->row_bounds[rank + 1];
+    if (shard) *shard = (osp_result_t)r->shard[rank];
+    return OSP_OK;
+}
+int osp_multi_result_copy_csr(osp_multi_result_t r_, int64_t *rowptr, uint32_t *colidx, void *vals) {
+    MultiResult *r = (MultiResult *)r_;
+    if (!r) return fail(OSP_ERR_ARG, "null result");
+    const size_t vs = r->dtype == OSP_F32 ? 4 : 8;
+    uint64_t base = 0;
+    for (size_t g = 0; g < r->shard.size(); g++) {
+        Result *sh = r->shard[g];
+        const uint64_t r0 = r->row_bounds[g], nr = r->row_bounds[g + 1] - r0, nz = sh->info.nnz_c;
+        const int st = osp_result_copy_csr((osp_result_t)sh, rowptr ? rowptr + r0 : nullptr, colidx ? colidx + base : nullptr,
+                                           vals ? (char *)vals + base * vs : nullptr, OSP_HOST);
+        if (st) return st;
+        if (rowptr) for (uint64_t i = 0; i <= nr; i++) rowptr[r0 + i] += (int64_t)base;   // (entry nr is rewritten by the next shard)
+        base += nz;
+    }
+    return OSP_OK;
+}
+int osp_multi_result_destroy(osp_multi_result_t r) {
+    delete (MultiResult *)r;
+    return OSP_OK;
 }
 
 int osp_result_info(osp_result_t r_, osp_result_info_t *info) {

@@ -332,6 +332,85 @@ class Context:
         return CsrResult(self, h)
 
 
+class MultiGpu:
+    """Several GPUs of one node behind ONE call (``osp_multi_*``): the k-sharded product of SURVEY.md 8e inside the library --
+    slabs of the shared dimension on their ranks, partial products copied GPU to GPU to the rank that owns their row while
+    the next panel multiplies, one merge per row range as the pieces arrive.  ``devices`` may name an ordinal more than
+    once (logical ranks sharing a GPU)."""
+
+    def __init__(self, devices):
+        self._h = None
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        _lib.check(_lib.lib().osp_multi_context_create(arr, len(devices), C.byref(h)))
+        self._h = h
+        self.devices = list(devices)
+        self._ops = None
+
+    def load(self, M, K, N, a_colptr, a_rowidx, a_vals, b_rowptr, b_colidx, b_vals):
+        """Cut k into slabs and put every rank's slab on its GPU (host numpy operands).  Replaces what was loaded before."""
+        dt = np.dtype(a_vals.dtype)
+        if dt not in _DT or np.dtype(b_vals.dtype) != dt:
+            raise TypeError("values must both be float32 or both float64")
+        arrs = [np.ascontiguousarray(a_colptr, np.int64), np.ascontiguousarray(a_rowidx, np.uint32), np.ascontiguousarray(a_vals, dt),
+                np.ascontiguousarray(b_rowptr, np.int64), np.ascontiguousarray(b_colidx, np.uint32), np.ascontiguousarray(b_vals, dt)]
+        if len(arrs[0]) != K + 1 or len(arrs[3]) != K + 1:
+            raise OspError(_lib.ERR_DIM, f"pointer arrays must have K+1={K + 1} entries (got {len(arrs[0])} and {len(arrs[3])})")
+        self.unload()
+        h = C.c_void_p()
+        _lib.check(_lib.lib().osp_multi_operands_create(self._h, _DT[dt], M, K, N, *[_ptr(a) for a in arrs], C.byref(h)))
+        self._ops, self._shape, self._dtype = h, (M, N), dt
+
+    def unload(self):
+        if self._ops is not None:
+            _lib.lib().osp_multi_operands_destroy(self._ops)
+            self._ops = None
+
+    def multiply(self, *, validate=False, partial_capacity=0, fetch=True):
+        """One product of the loaded operands.  Returns (info dict, (rowptr, colidx, vals) host arrays or None)."""
+        cfg = _lib.Config()
+        _lib.lib().osp_config_default(C.byref(cfg))
+        cfg.validate = int(bool(validate))
+        cfg.partial_capacity = int(partial_capacity or 0)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().osp_spgemm_multi(self._h, self._ops, C.byref(cfg), C.byref(h)))
+        try:
+            info = _lib.MultiInfo()
+            _lib.check(_lib.lib().osp_multi_result_info(h, C.byref(info)))
+            out = None
+            if fetch:
+                rowptr = np.zeros(self._shape[0] + 1, np.int64)
+                colidx = np.empty(info.nnz_c, np.uint32)
+                vals = np.empty(info.nnz_c, self._dtype)
+                _lib.check(_lib.lib().osp_multi_result_copy_csr(h, _ptr(rowptr), _ptr(colidx), _ptr(vals)))
+                out = (rowptr, colidx, vals)
+            return info.as_dict(), out
+        finally:
+            _lib.lib().osp_multi_result_destroy(h)
+
+    def spgemm_csc_csr(self, M, K, N, a_colptr, a_rowidx, a_vals, b_rowptr, b_colidx, b_vals, **kw):
+        self.load(M, K, N, a_colptr, a_rowidx, a_vals, b_rowptr, b_colidx, b_vals)
+        return self.multiply(**kw)
+
+    def close(self):
+        if self._h is not None:
+            self.unload()
+            _lib.lib().osp_multi_context_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---- ingest helpers (host, no GPU) ---------------------------------------------------------------
 def read_mtx(path, symmetric=False):
     """``readcoo`` (SimSpGEMM.cpp:55-100): returns (nrow, ncol, rows u32, cols u32, vals f64)."""
