@@ -81,6 +81,10 @@ def parse():
                     help="k-sharded product: what a rank sends -- raw = its partial products unmerged (one merge in all, bit-identical "
                          "to one GPU; default) | merged = its partial CSR (less to send when the product compresses well)")
     ap.add_argument("--force-dist", type=int, default=0, help="run the distributed code paths even with one rank (sanity check)")
+    ap.add_argument("--library-multi", type=int, default=1,
+                    help="N>1: rank 0 also measures the library's own multi-GPU product (osp_spgemm_multi: ONE process driving all N "
+                         "GPUs, partial products copied GPU to GPU behind the multiply, merge overlapped with the exchange) and "
+                         "reports it under decompositions.k_library; the other ranks wait")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal only: exchange staged through host memory, ranks may share a GPU")
     return ap.parse_args()
@@ -752,6 +756,40 @@ def main():
         results[mode] = r
         ctx.trim()
         torch.cuda.empty_cache()
+    if args.library_multi and "k" in modes:
+        # The same decomposition INSIDE the library (include/outerspace_spgemm.h, osp_multi_*): rank 0 drives all N GPUs from
+        # one process -- slabs resident on their GPUs, pipelined exchange, merge overlapped with it.  The other ranks have
+        # released their pools and wait at the barrier; the time is rank 0's wall clock around K products.
+        dist.barrier()
+        if rank == 0:
+            try:
+                host = [t.cpu().numpy() for t in (*csc, *csr)]
+                host[1] = host[1].view(np.uint32)
+                host[4] = host[4].view(np.uint32)
+                mg = S.MultiGpu([g % ndev for g in range(world)])
+                mg.load(n, n, n, *host)
+                del host
+                for _ in range(args.warmup):
+                    mg.multiply(fetch=False)
+                t0 = time.perf_counter()
+                linfos = [mg.multiply(fetch=False)[0] for _ in range(args.steps)]
+                ldt = time.perf_counter() - t0
+                lchk = check_sum(mg.multiply(fetch=False, checksum=True)[0]["val_sum"], want_sum, args.dtype, "library multi-GPU")
+                li = linfos[-1]
+                lms = ldt / args.steps * 1e3
+                results["k_library"] = {
+                    "value": li["nnz_c"] / (lms * 1e-3), "ms_per_step": lms, "nnz_c": li["nnz_c"], "partials": li["partials"],
+                    "result_check": lchk, "subpanels": li["subpanels"], "bytes_exchanged": li["bytes_exchanged"],
+                    "ms_upload_once": li["ms_upload"], "devices": [r["device"] for r in li["ranks"]],
+                    "ranks": [{k: r[k] for k in ("partials_local", "records_received", "bytes_sent", "nnz_c", "ms_symbolic",
+                                                 "ms_multiply_kernel", "ms_merge", "ms_total")} for r in li["ranks"]],
+                    "parallelism": f"k-sharded over {world} ranks inside the library (one process, one host thread per rank): partial "
+                                   "products copied GPU to GPU panel by panel behind the multiply, every row range merged as its pieces arrive"}
+                note(f"library multi-GPU product over {world} ranks: {lms:.1f} ms per step")
+                mg.close()
+            except Exception as e:   # reported, never fatal: the headline is the torch.distributed path
+                results["k_library"] = {"error": f"{type(e).__name__}: {e}"}
+        dist.barrier()
     head = results["k"] if "k" in results else results[modes[0]]
     if rank == 0:
         out.update({

@@ -894,7 +894,9 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     free_b += ctx->pooled_bytes;
     uint64_t cap = cap_cfg;
     // streaming: the panel's output buffer (at most one record per partial product) comes out of the same budget
-    if (cap == 0) cap = std::max<uint64_t>((uint64_t)(free_b * 0.85 / ((sink ? 4.4 : 3.3) * E)), 1ull << 20);
+    // (debugging aid: OSP_STAGE_FACTOR overrides the number of record sizes budgeted per staged partial product)
+    const double per_record = getenv("OSP_STAGE_FACTOR") ? atof(getenv("OSP_STAGE_FACTOR")) : (sink ? 4.4 : 3.3);
+    if (cap == 0) cap = std::max<uint64_t>((uint64_t)(free_b * 0.85 / (per_record * E)), 1ull << 20);
     cap = std::min<uint64_t>(cap, 0xfffffff0ull);  // staging positions are u32
     if (getenv("OSP_VERBOSE"))
         fprintf(stderr, "[osp] M=%llu N=%llu P=%llu nnzC<=%llu (%.1f GB) free %.1f GB -> staging capacity %llu partial products (%.1f GB)\n",
@@ -1210,7 +1212,11 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     // ("direct" rows, osp_split.h) when the operands allow 32-bit B offsets.  OSP_DIRECT=0 switches that off (every long
     // row is then split after the multiply, as the parts-merging entry points do), OSP_DIRECT_MAX=<partial products>
     // bounds the rows it applies to.
-    const bool direct = nnz && (uint64_t)nnz_b < 0xffffffffull && nnz < 0xffffffffull && !partials_only &&
+    // Small products keep the split: the plan costs a handful of launches and a read-back, which a product of a few
+    // milliseconds does not earn back (web-Google shape: 2.3 ms with the split, 2.7 with direct rows).  OSP_DIRECT_MIN_NNZ
+    // moves that boundary (the tests set it to 0, so that their small inputs take the direct path).
+    const uint64_t direct_min_nnz = getenv("OSP_DIRECT_MIN_NNZ") ? strtoull(getenv("OSP_DIRECT_MIN_NNZ"), nullptr, 10) : (8ull << 20);
+    const bool direct = nnz && nnz >= direct_min_nnz && (uint64_t)nnz_b < 0xffffffffull && nnz < 0xffffffffull && !partials_only &&
                         !(getenv("OSP_DIRECT") && atoi(getenv("OSP_DIRECT")) == 0);
     const uint64_t direct_max = getenv("OSP_DIRECT_MAX") ? strtoull(getenv("OSP_DIRECT_MAX"), nullptr, 10) : kSplitRowMax;
     DirectSrc dsrc{};
@@ -1229,8 +1235,9 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         uint64_t *offs_sorted = keep.get<uint64_t>(nnz + 1);
         uint64_t *scan_tmp = ss.get<uint64_t>(scan_scratch_entries(std::max<uint64_t>(nnz, M + 1)));
         // (row, k) order of A's non-zeros; the last sort pass also looks up each chunk's length
-        uint32_t *w = ss.get<uint32_t>(nnz);
-        uint32_t *bs = (rowwise || direct) ? ss.get<uint32_t>(nnz) : nullptr;
+        const bool table = rowwise || direct;   // keep the chunk table: (length, B row) pairs in `w`
+        uint32_t *w = ss.get<uint32_t>(table ? 2 * nnz : nnz);
+        uint32_t *bs = table ? w : nullptr;
         sym_chunk_len_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(a_colptr, b_rowptr, k0, k1, e0, nnz, w, bs);
         device_sort_rows<SymEpilogue>(a_rowidx + e0, nnz, std::max(1, bits_for(M)), ka, pa, kb, pb, hist, hist_tmp,
                                       SymEpilogue{w, bs, rows_sorted, perm, w_sorted, bs_sorted}, s, ctx->rank_atomic);

@@ -43,11 +43,14 @@ constexpr int kMulBatchAvg = 64;  // ... and at most this many per column on ave
 #ifndef OSP_MUL_TILE_MIN
 #define OSP_MUL_TILE_MIN 1024
 #endif
+// chunks whose destinations multiply_kernel forms together (chunk_dests), per path.  Measured on R-MAT-22: 1, 2, 4 or 8 at a
+// time make no difference to the direct rows (the kernel is bound by partially written lines, not by the gathers), while 4 / 2
+// cost 20 registers and two waves per SIMD, which the products WITHOUT long rows pay for (uniform: 8.0 -> 8.9 ms).
 #ifndef OSP_MUL_QU_MID
-#define OSP_MUL_QU_MID 4
+#define OSP_MUL_QU_MID 2
 #endif
 #ifndef OSP_MUL_QU_HUB
-#define OSP_MUL_QU_HUB 2
+#define OSP_MUL_QU_HUB 1
 #endif
 constexpr int kMulTileMin = OSP_MUL_TILE_MIN;  // B rows from this length on: products numbered in panels of the row (multiply_kernel)
 constexpr int kMulTileW = 128;                 // ... of this many entries (256: 77 registers, slower everywhere; 64: slower at Graph500 skew)
@@ -279,6 +282,19 @@ constexpr uint64_t kDirectBit = 1ull << 63;
 __device__ __forceinline__ uint64_t direct_desc(uint32_t rowbase, uint32_t celloff, uint32_t sh) {
     return kDirectBit | ((uint64_t)(sh & 31u) << 58) | ((uint64_t)(celloff & 0x3ffffffu) << 32) | (uint64_t)rowbase;
 }
+// A record of a direct row: OSP_NT_DIRECT=1 streams it past L2 like the chunk-major records; 0 leaves it to L2, where the
+// runs of consecutive chunks of a hub row -- adjacent in the range, written close in time -- can meet in one line.
+#ifndef OSP_NT_DIRECT
+#define OSP_NT_DIRECT 1
+#endif
+template <class T>
+__device__ __forceinline__ void store_direct_part(Part<T> *p, uint32_t col, T val) {
+#if OSP_NT_DIRECT
+    stream_store_part(p, col, val);
+#else
+    *p = Part<T>{col, val};
+#endif
+}
 template <class T>
 __device__ __forceinline__ void store_direct(const uint32_t *__restrict__ cells, Part<T> *__restrict__ qstage, uint64_t desc, uint32_t l,
                                              uint32_t bc, T v) {
@@ -286,7 +302,7 @@ __device__ __forceinline__ void store_direct(const uint32_t *__restrict__ cells,
     const uint32_t sh = (uint32_t)(desc >> 58) & 31u, co = (uint32_t)(desc >> 32) & 0x3ffffffu;
     const uint32_t rg = reinterpret_cast<const uint8_t *>(rb)[bc >> sh];
     const uint32_t delta = rb[co + rg];
-    stream_store_part(&qstage[(uint32_t)(delta + l)], bc, v);
+    store_direct_part(&qstage[(uint32_t)(delta + l)], bc, v);
 }
 
 // Where ONE entry of B's row (index ld in the row, column bc) goes in QU chunks at once.  off[i]: the chunk's staging
@@ -297,10 +313,9 @@ __device__ __forceinline__ void store_direct(const uint32_t *__restrict__ cells,
 template <class T, int QU>
 __device__ __forceinline__ void chunk_dests(const uint32_t *__restrict__ cells, const void *safe, Part<T> *__restrict__ stage,
                                             Part<T> *__restrict__ qstage, const uint64_t (&off)[QU], uint32_t lp, uint32_t ld,
-                                            uint32_t bc, Part<T> *(&dst)[QU]) {
+                                            uint32_t bc, Part<T> *(&dst)[QU], bool (&dir)[QU]) {
     const uint32_t *rb[QU];
     uint32_t rg[QU], delta[QU];
-    bool dir[QU];
 #pragma unroll
     for (int i = 0; i < QU; i++) {
         dir[i] = (off[i] & kDirectBit) && off[i] != kChunkSkip;   // (wave-uniform)
@@ -468,10 +483,14 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                         for (uint32_t u = 0; u < PER; u++) {
                             const uint32_t lrel = u * kWave + lane;
                             Part<T> *dst[QU];
-                            chunk_dests<T, QU>(cells, chunk_off, stage, qstage, off, lrel, pnl * W + lrel, bc[u], dst);
+                            bool dir[QU];
+                            chunk_dests<T, QU>(cells, chunk_off, stage, qstage, off, lrel, pnl * W + lrel, bc[u], dst, dir);
 #pragma unroll
                             for (int i = 0; i < QU; i++)
-                                if (lrel >= lo[i] && lrel < hi[i]) stream_store_part(dst[i], bc[u], av[i] * bv[u]);
+                                if (lrel >= lo[i] && lrel < hi[i]) {
+                                    if (dir[i]) store_direct_part(dst[i], bc[u], av[i] * bv[u]);
+                                    else stream_store_part(dst[i], bc[u], av[i] * bv[u]);
+                                }
                         }
                     }
                 }
@@ -510,10 +529,11 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                             off[i] = there ? wave_bcast(off_l, qi) : kChunkSkip;
                             ok[i] = in && off[i] != kChunkSkip && !(j == j0 && l < la) && !(j == j1 && l >= lb);
                         }
-                        chunk_dests<T, QU>(cells, chunk_off, stage, qstage, off, l, l, bc, dst);
+                        bool dir[QU];
+                        chunk_dests<T, QU>(cells, chunk_off, stage, qstage, off, l, l, bc, dst, dir);
 #pragma unroll
                         for (int i = 0; i < QU; i++)
-                            if (ok[i]) stream_store_part(dst[i], bc, av[i] * bv);
+                            if (ok[i]) { if (dir[i]) store_direct_part(dst[i], bc, av[i] * bv); else stream_store_part(dst[i], bc, av[i] * bv); }
                     }
                 }
             }

@@ -209,17 +209,23 @@ __global__ void ingest_ptr_kernel(const uint32_t *seg_sorted, uint64_t n, uint64
 // (The chunk lengths are looked up in CSC order beforehand -- sym_chunk_len_kernel -- where neighbouring
 // threads share a column; doing the column search here, in row order, cost 7.5 ms instead of 0.4.)
 struct SymEpilogue {
-    const uint32_t *w;   // chunk length per A entry, CSC order
-    const uint32_t *bs;  // first entry of its B row, CSC order
+    const uint32_t *w;   // chunk length per A entry, CSC order -- or, with the B rows wanted, (length, first entry of the B row)
+    const uint32_t *bs;  // non-null: `w` holds pairs (one 8-byte gather per chunk instead of two 4-byte ones from two arrays)
     uint32_t *rows_sorted, *perm, *w_sorted, *bs_sorted;
     __device__ void operator()(uint64_t t, uint32_t row, uint32_t pos) const {
         rows_sorted[t] = row;
         perm[t] = pos;
-        w_sorted[t] = w[pos];
-        if (bs_sorted) bs_sorted[t] = bs[pos];  // (row-wise variant only)
+        if (bs_sorted) {   // (row-wise variant and direct rows: the chunk table)
+            const uint2 p = reinterpret_cast<const uint2 *>(w)[pos];
+            w_sorted[t] = p.x;
+            bs_sorted[t] = p.y;
+        } else {
+            w_sorted[t] = w[pos];
+        }
     }
 };
-// w[t] = nnz(B[k,:]), bs[t] = b_rowptr[k] for the t-th non-zero of A's shard (CSC order, column k)
+// w[t] = nnz(B[k,:]) for the t-th non-zero of A's shard (CSC order, column k); with bs != nullptr: w holds the pairs
+// (nnz(B[k,:]), b_rowptr[k]) -- 2 * nnz words -- and bs itself is only the switch
 __global__ void sym_chunk_len_kernel(const int64_t *a_colptr, const int64_t *b_rowptr, uint64_t k0, uint64_t k1, int64_t e0,
                                      uint64_t nnz, uint32_t *w, uint32_t *bs) {
     // the block's 256 consecutive entries lie in a short range of columns: two full searches per block (first and last
@@ -234,8 +240,9 @@ __global__ void sym_chunk_len_kernel(const int64_t *a_colptr, const int64_t *b_r
     const uint64_t t = tb + threadIdx.x;
     if (t >= nnz) return;
     const uint64_t k = upper_bound_dev(a_colptr, krange[0], krange[1] + 1, e0 + (int64_t)t) - 1;
-    w[t] = (uint32_t)(b_rowptr[k + 1] - b_rowptr[k]);
-    if (bs) bs[t] = (uint32_t)b_rowptr[k];
+    const uint32_t len = (uint32_t)(b_rowptr[k + 1] - b_rowptr[k]);
+    if (bs) reinterpret_cast<uint2 *>(w)[t] = make_uint2(len, (uint32_t)b_rowptr[k]);   // pairs: `w` has 2 * nnz words then
+    else w[t] = len;
 }
 
 }  // namespace osp

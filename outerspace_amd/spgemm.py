@@ -366,8 +366,9 @@ class MultiGpu:
             _lib.lib().osp_multi_operands_destroy(self._ops)
             self._ops = None
 
-    def multiply(self, *, validate=False, partial_capacity=0, fetch=True):
-        """One product of the loaded operands.  Returns (info dict, (rowptr, colidx, vals) host arrays or None)."""
+    def multiply(self, *, validate=False, partial_capacity=0, fetch=True, checksum=False):
+        """One product of the loaded operands.  Returns (info dict, (rowptr, colidx, vals) host arrays or None).
+        checksum=True adds info["val_sum"] = the sum of all values of C, formed shard by shard on the GPUs (torch)."""
         cfg = _lib.Config()
         _lib.lib().osp_config_default(C.byref(cfg))
         cfg.validate = int(bool(validate))
@@ -378,13 +379,31 @@ class MultiGpu:
             info = _lib.MultiInfo()
             _lib.check(_lib.lib().osp_multi_result_info(h, C.byref(info)))
             out = None
+            extra = {}
+            if checksum:
+                import torch
+                from .distributed import _as_tensor
+                total = 0.0
+                for g in range(info.nranks):
+                    sh, va = C.c_void_p(), C.c_void_p()
+                    _lib.check(_lib.lib().osp_multi_result_shard(h, g, None, None, C.byref(sh)))
+                    _lib.check(_lib.lib().osp_result_device_ptrs(sh, None, None, C.byref(va)))
+                    n = info.rank[g].nnz_c
+                    if n:
+                        dev = torch.device("cuda", info.rank[g].device)
+                        f64 = self._dtype == np.float64
+                        total += float(_as_tensor(va.value, n, "<f8" if f64 else "<f4", dev, torch.float64 if f64 else torch.float32)
+                                       .sum(dtype=torch.float64))
+                extra["val_sum"] = total
             if fetch:
                 rowptr = np.zeros(self._shape[0] + 1, np.int64)
                 colidx = np.empty(info.nnz_c, np.uint32)
                 vals = np.empty(info.nnz_c, self._dtype)
                 _lib.check(_lib.lib().osp_multi_result_copy_csr(h, _ptr(rowptr), _ptr(colidx), _ptr(vals)))
                 out = (rowptr, colidx, vals)
-            return info.as_dict(), out
+            d = info.as_dict()
+            d.update(extra)
+            return d, out
         finally:
             _lib.lib().osp_multi_result_destroy(h)
 

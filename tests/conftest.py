@@ -2,6 +2,9 @@ import os
 
 # errors of the HIP runtime are silent at its default log level; a run that dies should say why
 os.environ.setdefault("AMD_LOG_LEVEL", "1")
+# products below 8 M non-zeros split their long rows after the multiply by default; the tests' small inputs must take the
+# direct-row path (osp_split.h, direct_plan_kernel) wherever it is not switched off on purpose
+os.environ.setdefault("OSP_DIRECT_MIN_NNZ", "0")
 import sys
 
 import pytest

@@ -13,14 +13,15 @@ python3 $R/bench.py --dtype f32 --cpu-baseline 0 --extras 0 > $O/bench_mild_f32.
 python3 $R/bench.py --workload webgoogle --cpu-baseline 0 --steps 20 --warmup 3 > $O/bench_webgoogle.json 2>/dev/null || exit 1
 python3 $R/bench.py --rmat g500 --scale 20 --stream-output --cpu-baseline 0 --steps 2 --warmup 1 > $O/bench_g500_20_streamed.json 2>/dev/null || exit 1
 for w in mild uniform; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$w -- python3 $R/bench.py --rmat $w --steps 3 --warmup 1 --cpu-baseline 0 --extras 0 > $O/ks_$w.json 2> $O/ks_$w.err || exit 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$w -- python3 $R/bench.py --rmat $w --steps 3 --warmup 1 --cpu-baseline 0 --extras 0 --ingest 0 > $O/ks_$w.json 2> $O/ks_$w.err || exit 1
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_g500 -- python3 $R/bench.py --rmat g500 --scale 20 --stream-output --steps 2 --warmup 1 --cpu-baseline 0 --extras 0 > $O/ks_g500.json 2> $O/ks_g500.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_webgoogle -- python3 $R/bench.py --workload webgoogle --steps 20 --warmup 3 --cpu-baseline 0 --extras 0 --ingest 0 > $O/ks_webgoogle.json 2> $O/ks_webgoogle.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_g500 -- python3 $R/bench.py --rmat g500 --scale 20 --stream-output --steps 2 --warmup 1 --cpu-baseline 0 --extras 0 --ingest 0 > $O/ks_g500.json 2> $O/ks_g500.err || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-baseline 0 --extras 0 > $O/pmc_$c.json 2> $O/pmc_$c.err || exit 1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-baseline 0 --extras 0 --ingest 0 > $O/pmc_$c.json 2> $O/pmc_$c.err || exit 1
 done
 # keep only the small summaries (the traces themselves are large)
-for w in mild uniform g500; do
+for w in mild uniform g500 webgoogle; do
   f=$(find $O/ks_$w -name "*kernel_stats.csv" | head -n 1)
   cp "$f" $O/ks_$w.kernel_stats.csv
   rm -rf $O/ks_$w
