@@ -573,28 +573,35 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
     pl.blkbase = sc.get<uint64_t>((uint64_t)nlong + 1); pl.hbase = sc.get<uint64_t>((uint64_t)nlong + 1);
     pl.vbase = sc.get<uint64_t>((uint64_t)nlong + 1); pl.cellbase = sc.get<uint64_t>((uint64_t)nlong + 1);
     unsigned long long *totals = (unsigned long long *)sc.get<uint64_t>(6);
-    OSP_HIP(hipMemsetAsync(totals, 0, 6 * sizeof(uint64_t), s));
     // debugging aid: OSP_SPLIT_ROW_MAX moves the boundary between the two split kernels (tests run both on small inputs)
     const uint64_t row_max = getenv("OSP_SPLIT_ROW_MAX") ? strtoull(getenv("OSP_SPLIT_ROW_MAX"), nullptr, 10) : kSplitRowMax;
     // no more ranges than make a range as narrow as the dense accumulators take (osp_split.h, kDenseBits): beyond that
     // a finer split only shortens the runs the scatter writes -- whatever a range of <= 1024 columns holds is summed
     // without a sort.  (Only bites when N < 2^22: 4096 ranges of 1024 columns.)
     const int bits_cap = getenv("OSP_SPLIT_BITS_CAP") ? atoi(getenv("OSP_SPLIT_BITS_CAP")) : std::max(colbits - kDenseBits, kSplitRowBits);
-    split_params_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(pl.p0.long_rows, nlong, row_off, colbits, row_max, bits_cap, ds ? ds->rowfirst : nullptr,
-                                                             ds ? ds->direct_max : 0ull, kCap, pl.hbits, pl.hmode, pl.nstretch, nseg, nhist, ncellh);
-    mode_totals_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(pl.p0.long_rows, nlong, row_off, pl.hmode, totals);
-    device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{pl.nstretch}, nlong, pl.blkbase, pl.hscan_tmp, s);
-    device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nseg}, nlong, pl.vbase, pl.hscan_tmp, s);
-    device_exclusive_scan<LoadU64, uint64_t>(LoadU64{nhist}, nlong, pl.hbase, pl.hscan_tmp, s);
-    if (ds) device_exclusive_scan<LoadU64, uint64_t>(LoadU64{ncellh}, nlong, pl.cellbase, pl.hscan_tmp, s);
     uint64_t ndcell = 0, tot[6] = {0, 0, 0, 0, 0, 0};
-    {
-        Gather g(s);
-        g.add(&pl.nh, (const uint64_t *)pl.hoff + nlong); g.add(&pl.nblocks, (const uint64_t *)pl.blkbase + nlong);
-        g.add(&pl.nvirt, (const uint64_t *)pl.vbase + nlong); g.add(&pl.ncell, (const uint64_t *)pl.hbase + nlong);
-        if (ds) g.add(&ndcell, (const uint64_t *)pl.cellbase + nlong);
-        for (int i = 0; i < 6; i++) g.add(&tot[i], (const uint64_t *)totals + i);
-        g.wait();
+    for (int attempt = 0; attempt < 2; attempt++) {
+        split_params_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(pl.p0.long_rows, nlong, row_off, colbits, row_max, bits_cap, ds ? ds->rowfirst : nullptr,
+                                                                 ds ? ds->direct_max : 0ull, kCap, pl.hbits, pl.hmode, pl.nstretch, nseg, nhist, ncellh);
+        OSP_HIP(hipMemsetAsync(totals, 0, 6 * sizeof(uint64_t), s));
+        mode_totals_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(pl.p0.long_rows, nlong, row_off, pl.hmode, totals);
+        device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{pl.nstretch}, nlong, pl.blkbase, pl.hscan_tmp, s);
+        device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nseg}, nlong, pl.vbase, pl.hscan_tmp, s);
+        device_exclusive_scan<LoadU64, uint64_t>(LoadU64{nhist}, nlong, pl.hbase, pl.hscan_tmp, s);
+        if (ds) device_exclusive_scan<LoadU64, uint64_t>(LoadU64{ncellh}, nlong, pl.cellbase, pl.hscan_tmp, s);
+        ndcell = 0;
+        {
+            Gather g(s);
+            g.add(&pl.nh, (const uint64_t *)pl.hoff + nlong); g.add(&pl.nblocks, (const uint64_t *)pl.blkbase + nlong);
+            g.add(&pl.nvirt, (const uint64_t *)pl.vbase + nlong); g.add(&pl.ncell, (const uint64_t *)pl.hbase + nlong);
+            if (ds) g.add(&ndcell, (const uint64_t *)pl.cellbase + nlong);
+            for (int i = 0; i < 6; i++) g.add(&tot[i], (const uint64_t *)totals + i);
+            g.wait();
+        }
+        // the cells of a panel are addressed with 32 bits (and are device memory beside the staging buffers): a panel whose
+        // plan would not fit splits its long rows after the multiply instead
+        if (!ds || ndcell < 0xffffffffull) break;
+        ds = nullptr;
     }
     for (int m = 0; m < 3; m++) { pl.mode_rows[m] = tot[m]; pl.mode_partials[m] = tot[3 + m]; }
     if (pl.nh >= 0xffffffffull) throw Error(OSP_ERR_CAPACITY, "long rows of one panel exceed 2^32 partial products");
@@ -895,7 +902,10 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     uint64_t cap = cap_cfg;
     // streaming: the panel's output buffer (at most one record per partial product) comes out of the same budget
     // (debugging aid: OSP_STAGE_FACTOR overrides the number of record sizes budgeted per staged partial product)
-    const double per_record = getenv("OSP_STAGE_FACTOR") ? atof(getenv("OSP_STAGE_FACTOR")) : (sink ? 4.4 : 3.3);
+    // what a staged partial product needs: its record in the staging buffer, for 9 of 10 another one in the second buffer,
+    // and a few per cent for tile tables and the cells of the direct rows -- 2.0 record sizes; 2.6 budgets 30 % on top of
+    // that (3.3 until round 3: R-MAT-22 mild ran as 4 panels, now 3: one panel's planning, launches and read-backs less)
+    const double per_record = getenv("OSP_STAGE_FACTOR") ? atof(getenv("OSP_STAGE_FACTOR")) : (sink ? 3.7 : 2.6);
     if (cap == 0) cap = std::max<uint64_t>((uint64_t)(free_b * 0.85 / (per_record * E)), 1ull << 20);
     cap = std::min<uint64_t>(cap, 0xfffffff0ull);  // staging positions are u32
     if (getenv("OSP_VERBOSE"))

@@ -322,6 +322,12 @@ __device__ __forceinline__ void chunk_dests(const uint32_t *__restrict__ cells, 
         rb[i] = dir[i] ? cells + (uint32_t)off[i] : reinterpret_cast<const uint32_t *>(safe);
         const uint32_t sh = (uint32_t)(off[i] >> 58) & 31u;
         rg[i] = reinterpret_cast<const uint8_t *>(rb[i])[dir[i] ? bc >> sh : 0u];
+#ifdef OSP_EXP_EXTRA_GATHER   // experiment only: one more gather of the same kind per store (is the kernel bound by its gathers?)
+        {
+            const uint32_t extra = reinterpret_cast<const uint8_t *>(rb[i])[dir[i] ? (bc >> sh) ^ 1u : 0u];
+            asm volatile("" ::"v"(extra));
+        }
+#endif
     }
 #pragma unroll
     for (int i = 0; i < QU; i++) {

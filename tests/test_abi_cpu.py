@@ -34,6 +34,24 @@ def test_struct_layouts_match_header():
     assert _lib.lib().osp_status_string(233).decode().startswith("duplicate")
 
 
+def test_ctypes_structs_have_the_sizes_the_c_compiler_gives(tmp_path):
+    """Every struct the Python binding mirrors, measured by the C compiler on the header itself (an appended field that the
+    binding forgets would shift everything behind it)."""
+    import ctypes
+    import subprocess
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "outerspace_spgemm.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(osp_config_t), sizeof(osp_result_info_t), sizeof(osp_panel_t), '
+                   'sizeof(osp_multi_rank_info_t), sizeof(osp_multi_info_t), offsetof(osp_result_info_t, rank_atomic), '
+                   'offsetof(osp_multi_info_t, rank)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [ctypes.sizeof(_lib.Config), ctypes.sizeof(_lib.ResultInfo), ctypes.sizeof(_lib.Panel), ctypes.sizeof(_lib.MultiRankInfo),
+            ctypes.sizeof(_lib.MultiInfo), _lib.ResultInfo.rank_atomic.offset, _lib.MultiInfo.rank.offset]
+    assert got == want, (got, want)
+
+
 def test_no_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():
