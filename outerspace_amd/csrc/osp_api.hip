@@ -630,6 +630,19 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
                                                            colbits, kCap, ds->rowfirst, ds->off, ds->bs, ds->perm, ds->b_colidx, pl.vrow_off,
                                                            pl.vcol0, pl.vcol1, pl.cells, ds->chunk_off);
         tm.end(PH_PLAN_K);
+#ifdef OSP_PLAN_PROF
+        if (getenv("OSP_VERBOSE")) {
+            unsigned long long hp[8] = {0}, z[8] = {0};
+            OSP_HIP(hipStreamSynchronize(s));
+            (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(osp_plan_prof), sizeof(hp));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(osp_plan_prof), z, sizeof(z));
+            double tot = 0;
+            for (int k = 0; k < 6; k++) tot += (double)hp[k];
+            fprintf(stderr, "[osp]   planner cycles: header %.1f %%, chunk descriptors %.1f %%, histogram pass %.1f %%, grouping %.1f %%, cell pass %.1f %%, "
+                            "prefixes + output %.1f %%\n", 100 * hp[0] / tot, 100 * hp[1] / tot, 100 * hp[2] / tot, 100 * hp[3] / tot, 100 * hp[4] / tot,
+                    100 * hp[5] / tot);
+        }
+#endif
         res->info.direct_plan_launches++;
         dbg_sync(s, "plan of the direct rows");
     }

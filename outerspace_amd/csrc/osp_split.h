@@ -62,6 +62,7 @@ constexpr uint8_t kModeSplitRow = 0, kModeStretch = 1, kModeDirect = 2;
 constexpr int kDirectThreads = 256;
 constexpr int kDirectCells = 4096;     // LDS words of direct_plan_kernel's (chunk, range) cells: counts and in-chunk starts
 constexpr int kDirectMaxRanges = 255;  // ranges per direct row (a byte per fine bin names the range)
+constexpr uint64_t kDirectRowCells = 1ull << 19;  // (chunk, range) cells of ONE direct row at most
 // per long row h: b = number of split bits, the mode, and the sizes that get scanned.
 // rowfirst != nullptr: the row's chunks are known (first chunk of every row in (row, k) order), so rows of at most
 // direct_max partial products that one workgroup could split are planned as direct rows instead: nseg = an upper bound
@@ -80,13 +81,15 @@ __global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const
     const bool big = U > row_max || b > kSplitRowBits;
     const uint32_t ns = big ? (uint32_t)((U + kSplitJob - 1) / kSplitJob) : 0u;  // 0 stretches = one-workgroup row
     const uint64_t nranges = 2 * U / cap + 2;
-    const bool direct = rowfirst != nullptr && !big && U <= direct_max && nranges <= (uint64_t)kDirectMaxRanges;
+    const uint64_t nc = rowfirst != nullptr ? (uint64_t)(rowfirst[rows[h] + 1] - rowfirst[rows[h]]) : 0ull;
+    // (a row of very many tiny chunks -- nc * nranges cells -- would keep ONE workgroup of the planner busy for milliseconds,
+    // block of chunks after block of chunks: such a row is cheaper to split)
+    const bool direct = rowfirst != nullptr && !big && U <= direct_max && nranges <= (uint64_t)kDirectMaxRanges && nc * nranges <= kDirectRowCells;
     hbits[h] = (uint8_t)b;
     hmode[h] = direct ? kModeDirect : big ? kModeStretch : kModeSplitRow;
     nstretch[h] = ns;
     nseg[h] = direct ? (uint32_t)nranges : 1u << b;
     nhist[h] = (uint64_t)ns << b;
-    const uint64_t nc = direct ? (uint64_t)(rowfirst[rows[h] + 1] - rowfirst[rows[h]]) : 0ull;
     ncell[h] = direct ? ((1ull << b) + 3) / 4 + nc * nranges : 0ull;
 }
 struct HeavyLenIf {   // partial products of long row h if it has mode `mode` (else 0): how much each path handles
@@ -597,6 +600,16 @@ __device__ __forceinline__ uint32_t direct_find_chunk(const uint32_t *cst, uint3
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cst[mid] <= i) lo = mid; else hi = mid; }
     return lo;
 }
+// Phase timing of the planner (-DOSP_PLAN_PROF, a development build: OSP_VERBOSE prints the shares after every product):
+// thread 0 of every workgroup adds the cycles between marks to osp_plan_prof[phase].  Compiled out of the library.
+#ifdef OSP_PLAN_PROF
+__device__ unsigned long long osp_plan_prof[8];
+#define OSP_PLAN_MARK(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); atomicAdd(&osp_plan_prof[k], now_ - prof_t); prof_t = now_; } } while (0)
+#define OSP_PLAN_DECL unsigned long long prof_t = clock64();
+#else
+#define OSP_PLAN_MARK(k)
+#define OSP_PLAN_DECL
+#endif
 __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
     const uint32_t *__restrict__ rows, uint32_t nlong, const uint8_t *__restrict__ hmode, const uint8_t *__restrict__ hbits,
     const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ vbase, const uint64_t *__restrict__ hoff,
@@ -617,6 +630,7 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
     __shared__ uint32_t s_T;
     const uint32_t h = blockIdx.x;
     if (h >= nlong || hmode[h] != kModeDirect) return;
+    OSP_PLAN_DECL
     const unsigned tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     const uint32_t i = rows[h];
     const uint32_t c0 = rowfirst[i], nc = rowfirst[i + 1] - c0;
@@ -670,11 +684,13 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
     };
     for (uint32_t d = tid; d <= nfine; d += NT) hist[d] = 0;
     __syncthreads();
+    OSP_PLAN_MARK(0);   // row header
     // ---- 1. histogram over the fine bins
     uint32_t have_cb = 0, have_nb = 0, have_E = 0;   // the block of chunks whose descriptors are in LDS
     for (uint32_t cb = 0; cb < nc; cb += CBL) {
         const uint32_t nb = min((uint32_t)CBL, nc - cb);
         const uint32_t E = load_block(cb, nb);
+        OSP_PLAN_MARK(1);   // chunk descriptors
         have_cb = cb; have_nb = nb; have_E = E;
         for_entries(nb, E, [&](uint32_t, uint32_t col, bool valid) {
             const uint32_t bin = valid ? col >> sh : 0xffffffffu;
@@ -682,6 +698,7 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
             if (wave_run_head(bin, valid, runlen)) atomicAdd(&hist[bin], runlen);
         });
         __syncthreads();   // before the next block's descriptors replace these
+        OSP_PLAN_MARK(2);   // histogram pass
     }
     // ---- 2. greedy grouping into ranges of at most `cap`: prefix sums, the bin every range starting at d ends before,
     // then one thread follows that chain (a few steps instead of one per bin)
@@ -725,6 +742,7 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
     }
     __syncthreads();
     for (uint32_t d = tid; d < lutw * 4; d += NT) reinterpret_cast<uint8_t *>(rb)[d] = d < nfine ? lut[d] : (uint8_t)0;
+    OSP_PLAN_MARK(3);   // grouping, segment tables
     // ---- 3. cells, a block of chunks at a time
     const uint32_t CB = max(1u, min((uint32_t)CBL, (uint32_t)kCellsLds / T));
     // column prefixes by (group of chunks, range): G groups of S chunks each
@@ -736,12 +754,14 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
         if (cb != have_cb || nb != have_nb) E = load_block(cb, nb);   // (most rows: one block, still there from the histogram)
         else __syncthreads();
         have_cb = cb; have_nb = nb; have_E = E;
+        OSP_PLAN_MARK(1);
         for_entries(nb, E, [&](uint32_t cl, uint32_t col, bool valid) {
             const uint32_t key = valid ? cl * 256u + (uint32_t)lut[col >> sh] : 0xffffffffu;   // (chunk, range): T <= 255
             uint32_t runlen;
             if (wave_run_head(key, valid, runlen)) atomicAdd(&cellm[(key >> 8) * T + (key & 255u)], runlen);
         });
         __syncthreads();
+        OSP_PLAN_MARK(4);   // cell pass
         // where every range starts inside its chunk
         for (uint32_t cl = tid; cl < nb; cl += NT) {
             uint32_t run = 0;
@@ -772,6 +792,7 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
         for (uint32_t cl = tid; cl < nb; cl += NT)
             chunk_off[perm[c0 + cb + cl]] = direct_desc((uint32_t)cellbase[h], lutw + (cb + cl) * Ta, (uint32_t)sh);
         __syncthreads();   // the block's cells and descriptors have been read
+        OSP_PLAN_MARK(5);   // prefixes, cells and descriptors out
     }
 }
 }  // namespace osp

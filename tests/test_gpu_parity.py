@@ -1044,3 +1044,22 @@ def test_two_devices_one_thread():
         r0b = c0.spgemm_csc_csr(n, n, n, *acsc, *bcsr)
         for r in (r1, r0b):
             assert np.array_equal(r.rowptr, r0.rowptr) and np.array_equal(r.colidx, r0.colidx) and np.array_equal(r.vals, r0.vals)
+
+
+@pytest.mark.parametrize("K", [3000, 60000])
+def test_long_row_of_tiny_chunks(port, _ctx_shared, K):
+    """One output row fed by K chunks of one or two entries (a dense row of A times a near-diagonal B): many (chunk, range)
+    cells per product.  Below the planner's per-row cell budget the row is written directly (K = 3000), above it the row is
+    split after the multiply (K = 60000) -- same bits either way, no pathological planning time."""
+    rng = np.random.default_rng(11)
+    M, N = 3, 50000
+    a = (np.zeros(K, np.uint32), np.arange(K, dtype=np.uint32), rng.uniform(0.5, 1.5, K))
+    b_rows = np.concatenate([np.arange(K), np.arange(0, K, 3)]).astype(np.uint32)
+    b_cols = np.concatenate([(np.arange(K) * 7919) % N, (np.arange(0, K, 3) * 104729 + 1) % N]).astype(np.uint32)
+    key = np.unique(b_rows.astype(np.int64) * N + b_cols)
+    b = ((key // N).astype(np.uint32), (key % N).astype(np.uint32), rng.uniform(0.5, 1.5, len(key)))
+    got, want = run_both(_ctx_shared, port, M, K, N, a, b, np.float64)
+    assert got.info["heavy_rows"] == 1
+    assert got.info["direct_rows"] == (1 if K == 3000 else 0)
+    assert_same(got, want)
+    got.close()
