@@ -80,6 +80,8 @@ def parse():
     ap.add_argument("--k-exchange", default="raw", choices=["raw", "merged"],
                     help="k-sharded product: what a rank sends -- raw = its partial products unmerged (one merge in all, bit-identical "
                          "to one GPU; default) | merged = its partial CSR (less to send when the product compresses well)")
+    ap.add_argument("--library-multi-only", type=int, default=0, help="(child mode of --library-multi) ranks of the library's own product")
+    ap.add_argument("--library-multi-timeout", type=int, default=600, help="seconds the child of --library-multi may take")
     ap.add_argument("--force-dist", type=int, default=0, help="run the distributed code paths even with one rank (sanity check)")
     ap.add_argument("--library-multi", type=int, default=1,
                     help="N>1: rank 0 also measures the library's own multi-GPU product (osp_spgemm_multi: ONE process driving all N "
@@ -543,8 +545,73 @@ def emit(obj):
     os.write(_JSON_FD if _JSON_FD is not None else 1, line)
 
 
+def library_multi_child(args, world):
+    """Run `bench.py --library-multi-only WORLD` as a child process and return its JSON (or an error record)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR",
+                                                             "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "OSP_BENCH_SPAWNED")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--library-multi-only", str(world), "--steps", str(args.steps), "--warmup",
+           str(args.warmup), "--scale", str(args.scale), "--edge-factor", str(args.edge_factor), "--rmat", args.rmat, "--seed",
+           str(args.seed), "--dtype", args.dtype, "--workload", args.workload]
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=args.library_multi_timeout)
+        lines = r.stdout.decode(errors="replace").strip().splitlines()
+        if r.returncode != 0 or not lines:
+            return {"error": f"child exited with status {r.returncode}"}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": f"no result within {args.library_multi_timeout} s"}
+    except (OSError, ValueError) as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def library_multi_only(args):
+    """Child mode: the library's own multi-GPU product (osp_spgemm_multi) over `--library-multi-only` ranks spread over the
+    visible GPUs, K timed products with the slabs resident; one JSON object on stdout."""
+    import torch
+    from outerspace_amd import generators as gen
+    from outerspace_amd import spgemm as S
+    world = args.library_multi_only
+    ndev = torch.cuda.device_count()
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    tdtype = torch.float64 if args.dtype == "f64" else torch.float32
+    abcd = gen.RMAT_PRESETS[args.rmat] if args.rmat in gen.RMAT_PRESETS else tuple(float(x) for x in args.rmat.split(","))
+    if args.workload == "webgoogle":
+        n, csr, csc = webgoogle_operands(args.seed, device, tdtype)
+    else:
+        n, csr, csc = rmat_device(args.scale, args.edge_factor, abcd, args.seed, device, tdtype)
+    want_sum = expected_value_sum(n, csr, csc, device)
+    host = [t.cpu().numpy() for t in (*csc, *csr)]
+    host[1] = host[1].view(np.uint32)
+    host[4] = host[4].view(np.uint32)
+    del csr, csc
+    torch.cuda.empty_cache()
+    mg = S.MultiGpu([g % ndev for g in range(world)])
+    mg.load(n, n, n, *host)
+    del host
+    for _ in range(args.warmup):
+        mg.multiply(fetch=False)
+    t0 = time.perf_counter()
+    infos = [mg.multiply(fetch=False)[0] for _ in range(args.steps)]
+    dt = time.perf_counter() - t0
+    chk = check_sum(mg.multiply(fetch=False, checksum=True)[0]["val_sum"], want_sum, args.dtype, "library multi-GPU")
+    li = infos[-1]
+    ms = dt / args.steps * 1e3
+    out = {"value": li["nnz_c"] / (ms * 1e-3), "ms_per_step": ms, "nnz_c": li["nnz_c"], "partials": li["partials"], "result_check": chk,
+           "subpanels": li["subpanels"], "bytes_exchanged": li["bytes_exchanged"], "ms_upload_once": li["ms_upload"],
+           "devices": [r["device"] for r in li["ranks"]], "gpus_visible": ndev,
+           "ranks": [{k: r[k] for k in ("partials_local", "records_received", "bytes_sent", "nnz_c", "ms_symbolic", "ms_multiply_kernel",
+                                        "ms_merge", "ms_total")} for r in li["ranks"]],
+           "parallelism": f"k-sharded over {world} ranks inside the library (one process, one host thread per rank): partial products "
+                          "copied GPU to GPU panel by panel behind the multiply, every row range merged as its pieces arrive"}
+    mg.close()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
+    if args.library_multi_only:
+        return library_multi_only(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))   # before anything here touches the GPU
     claim_stdout()
@@ -757,38 +824,14 @@ def main():
         ctx.trim()
         torch.cuda.empty_cache()
     if args.library_multi and "k" in modes:
-        # The same decomposition INSIDE the library (include/outerspace_spgemm.h, osp_multi_*): rank 0 drives all N GPUs from
-        # one process -- slabs resident on their GPUs, pipelined exchange, merge overlapped with it.  The other ranks have
-        # released their pools and wait at the barrier; the time is rank 0's wall clock around K products.
+        # The same decomposition INSIDE the library (include/outerspace_spgemm.h, osp_multi_*): ONE process drives all N GPUs --
+        # slabs resident on their GPUs, pipelined exchange, merge overlapped with it.  It runs in a child process of rank 0
+        # with a time limit (this path has never run on more than one physical GPU at the builder's: whatever it does there
+        # must not cost the line above its numbers); the other ranks have released their pools and wait at the barrier.
         dist.barrier()
         if rank == 0:
-            try:
-                host = [t.cpu().numpy() for t in (*csc, *csr)]
-                host[1] = host[1].view(np.uint32)
-                host[4] = host[4].view(np.uint32)
-                mg = S.MultiGpu([g % ndev for g in range(world)])
-                mg.load(n, n, n, *host)
-                del host
-                for _ in range(args.warmup):
-                    mg.multiply(fetch=False)
-                t0 = time.perf_counter()
-                linfos = [mg.multiply(fetch=False)[0] for _ in range(args.steps)]
-                ldt = time.perf_counter() - t0
-                lchk = check_sum(mg.multiply(fetch=False, checksum=True)[0]["val_sum"], want_sum, args.dtype, "library multi-GPU")
-                li = linfos[-1]
-                lms = ldt / args.steps * 1e3
-                results["k_library"] = {
-                    "value": li["nnz_c"] / (lms * 1e-3), "ms_per_step": lms, "nnz_c": li["nnz_c"], "partials": li["partials"],
-                    "result_check": lchk, "subpanels": li["subpanels"], "bytes_exchanged": li["bytes_exchanged"],
-                    "ms_upload_once": li["ms_upload"], "devices": [r["device"] for r in li["ranks"]],
-                    "ranks": [{k: r[k] for k in ("partials_local", "records_received", "bytes_sent", "nnz_c", "ms_symbolic",
-                                                 "ms_multiply_kernel", "ms_merge", "ms_total")} for r in li["ranks"]],
-                    "parallelism": f"k-sharded over {world} ranks inside the library (one process, one host thread per rank): partial "
-                                   "products copied GPU to GPU panel by panel behind the multiply, every row range merged as its pieces arrive"}
-                note(f"library multi-GPU product over {world} ranks: {lms:.1f} ms per step")
-                mg.close()
-            except Exception as e:   # reported, never fatal: the headline is the torch.distributed path
-                results["k_library"] = {"error": f"{type(e).__name__}: {e}"}
+            results["k_library"] = library_multi_child(args, world)
+            note(f"library multi-GPU product over {world} ranks: {results['k_library'].get('ms_per_step', results['k_library'])}")
         dist.barrier()
     head = results["k"] if "k" in results else results[modes[0]]
     if rank == 0:
