@@ -1061,8 +1061,12 @@ template <class T> struct OuterProducer : Producer<T> {
         const uint64_t nblocks = (count + kMulPerBlock - 1) / kMulPerBlock;
         dbg_sync(s, "panel columns + scan");
         tm.begin(PH_MUL_K);
-        multiply_kernel<T><<<(unsigned)nblocks, kMulThreads, 0, s>>>(a_vals, b_colidx, b_vals, b_rowptr, chunk_off, e0,
-                                                                     a_start, a_cnt, prod_off, k0, nk, count, base, stage, cells, qstage);
+        if (cells)
+            multiply_kernel<T, true><<<(unsigned)nblocks, kMulThreads, 0, s>>>(a_vals, b_colidx, b_vals, b_rowptr, chunk_off, e0,
+                                                                             a_start, a_cnt, prod_off, k0, nk, count, base, stage, cells, qstage);
+        else
+            multiply_kernel<T, false><<<(unsigned)nblocks, kMulThreads, 0, s>>>(a_vals, b_colidx, b_vals, b_rowptr, chunk_off, e0,
+                                                                              a_start, a_cnt, prod_off, k0, nk, count, base, stage, nullptr, nullptr);
         tm.end(PH_MUL_K);
         dbg_sync(s, "multiply");
         res->info.multiply_launches++;

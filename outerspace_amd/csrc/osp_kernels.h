@@ -25,7 +25,12 @@ namespace osp {
 // tool, level-1 tiles at full fill: 1536 x 256 threads x 5 per CU 2.40 ms; 1792 x 256 x 4 2.65; 2048 x 256 x 4 2.75;
 // 1920 x 320 x 4 3.30; 2304 x 384 x 3 3.96; 3072 x 512 x 2 3.22.)
 template <class T> struct TileCap;
-template <> struct TileCap<float> { static constexpr int value = 1536; };
+#ifndef OSP_TILE_CAP_F32
+#define OSP_TILE_CAP_F32 1792
+#endif
+// (f32 values alias 4 bytes per entry, not 8: the same 31 KB of LDS hold a seventh more entries, and a tile costs a ticket
+// and a look-back whatever it holds)
+template <> struct TileCap<float> { static constexpr int value = OSP_TILE_CAP_F32; };
 template <> struct TileCap<double> { static constexpr int value = 1536; };
 constexpr int kMergeThreads = 256;
 constexpr int kTileMaxRows = kMergeThreads - 1;  // rows per tile: 8 row bits in the sort key, one row offset per thread
@@ -310,10 +315,15 @@ __device__ __forceinline__ void store_direct(const uint32_t *__restrict__ cells,
 // dependent loads per entry (range of the column, cell of the range); written one chunk after the other, every store
 // waits for both, and that latency -- not bandwidth -- bounds the kernel (R-MAT-22: 10.1 -> 17.3 ms per launch).  Here the
 // loads of all QU chunks go out together, branch-free (a chunk that is not direct reads a word of `safe` and ignores it).
-template <class T, int QU>
+template <class T, int QU, bool DIRECT>
 __device__ __forceinline__ void chunk_dests(const uint32_t *__restrict__ cells, const void *safe, Part<T> *__restrict__ stage,
                                             Part<T> *__restrict__ qstage, const uint64_t (&off)[QU], uint32_t lp, uint32_t ld,
                                             uint32_t bc, Part<T> *(&dst)[QU], bool (&dir)[QU]) {
+    if constexpr (!DIRECT) {   // a launch without direct rows: every chunk has a plain staging offset
+#pragma unroll
+        for (int i = 0; i < QU; i++) { dir[i] = false; dst[i] = &stage[off[i] + lp]; }
+        return;
+    }
     const uint32_t *rb[QU];
     uint32_t rg[QU], delta[QU];
 #pragma unroll
@@ -343,7 +353,9 @@ __device__ __forceinline__ void chunk_dests(const uint32_t *__restrict__ cells, 
 // then by A entry j, then by B entry l; wave `wv` owns products [wv*kMulPerWave, ...).  For each
 // column it touches, the B row is held in registers (one entry per lane) and every A entry's chunk
 // is written with consecutive lanes on consecutive addresses.
-template <class T>
+// DIRECT: the launch has direct rows (descriptors among the chunk offsets); without them the kernel is instantiated without
+// that code (64 registers instead of 68: one more wave per SIMD, which the products of short rows notice)
+template <class T, bool DIRECT = true>
 __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
     const T *__restrict__ a_vals, const uint32_t *__restrict__ b_colidx, const T *__restrict__ b_vals,
     const int64_t *__restrict__ b_rowptr, const uint64_t *__restrict__ chunk_off, int64_t e0,
@@ -411,7 +423,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                         const uint32_t bc = b_colidx[bsx + l];
                         const T pv = a_vals[e] * b_vals[bsx + l];
                         if (raw != kChunkSkip) {
-                            if (raw & kDirectBit) store_direct(cells, qstage, raw, l, bc, pv);
+                            if (DIRECT && (raw & kDirectBit)) store_direct(cells, qstage, raw, l, bc, pv);
                             else stream_store_part(&stage[raw - base + l], bc, pv);
                         }
                     }
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                     if (jm <= tj1) {
                         av_l = a_vals[as + jm];
                         const uint64_t raw = chunk_off[as + jm - (uint64_t)e0];
-                        off_l = (raw & kDirectBit) ? raw : raw - base + (uint64_t)pnl * W;  // (kChunkSkip and descriptors: as they are)
+                        off_l = ((raw & kDirectBit) && (DIRECT || raw == kChunkSkip)) ? raw : raw - base + (uint64_t)pnl * W;  // (kChunkSkip and descriptors: as they are)
                     }
                     const uint32_t cj = (uint32_t)min((uint64_t)kWave, tj1 - jb + 1);
                     constexpr int QU = OSP_MUL_QU_HUB;   // chunks whose destinations are formed together (chunk_dests): with two entries per lane, twice as many chains
@@ -490,7 +502,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                             const uint32_t lrel = u * kWave + lane;
                             Part<T> *dst[QU];
                             bool dir[QU];
-                            chunk_dests<T, QU>(cells, chunk_off, stage, qstage, off, lrel, pnl * W + lrel, bc[u], dst, dir);
+                            chunk_dests<T, QU, DIRECT>(cells, chunk_off, stage, qstage, off, lrel, pnl * W + lrel, bc[u], dst, dir);
 #pragma unroll
                             for (int i = 0; i < QU; i++)
                                 if (lrel >= lo[i] && lrel < hi[i]) {
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                 if (jm <= j1) {
                     av_l = a_vals[as + jm];
                     const uint64_t raw = chunk_off[as + jm - (uint64_t)e0];
-                    off_l = (raw & kDirectBit) ? raw : raw - base;  // (kChunkSkip and descriptors: as they are)
+                    off_l = ((raw & kDirectBit) && (DIRECT || raw == kChunkSkip)) ? raw : raw - base;  // (kChunkSkip and descriptors: as they are)
                 }
                 const uint32_t cj = (uint32_t)min((uint64_t)kWave, j1 - jb + 1);
                 for (uint32_t l0 = 0; l0 < nb; l0 += kWave) {
@@ -536,7 +548,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                             ok[i] = in && off[i] != kChunkSkip && !(j == j0 && l < la) && !(j == j1 && l >= lb);
                         }
                         bool dir[QU];
-                        chunk_dests<T, QU>(cells, chunk_off, stage, qstage, off, l, l, bc, dst, dir);
+                        chunk_dests<T, QU, DIRECT>(cells, chunk_off, stage, qstage, off, l, l, bc, dst, dir);
 #pragma unroll
                         for (int i = 0; i < QU; i++)
                             if (ok[i]) { if (dir[i]) store_direct_part(dst[i], bc, av[i] * bv); else stream_store_part(dst[i], bc, av[i] * bv); }
@@ -558,7 +570,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                     const uint64_t e = as + j;
                     const uint64_t raw = chunk_off[e - (uint64_t)e0];
                     if (raw != kChunkSkip) {
-                        if (raw & kDirectBit) store_direct(cells, qstage, raw, l, bc, a_vals[e] * bv);
+                        if (DIRECT && (raw & kDirectBit)) store_direct(cells, qstage, raw, l, bc, a_vals[e] * bv);
                         else stream_store_part(&stage[raw - base + l], bc, a_vals[e] * bv);
                     }
                 }
@@ -650,15 +662,18 @@ constexpr int kDigits = 1 << kDigitBits;      // 1024 buckets
 // the 8 bytes per entry that do not hold the sorted keys -- (key0, pos0, pad) when the sorted keys sit in
 // buffer 1, (pad, key1, pos1) when they sit in buffer 0; that is what `pad` is for.  Before the first pass the
 // hash set that counts the tile's distinct keys uses everything behind key0 (10 bytes = 2.5 words per entry).
+// f32: values are 4 bytes and fit the idle KEY buffer alone, so `pad` shrinks to nothing (12 bytes per entry, hash table 2 words).
 // After the last pass the digit counters are dead and hold `rank` (output slot per sorted position).
 template <class T, int NT, int CAP = TileCap<T>::value>
 struct alignas(8) MergeSmem {
     static constexpr int kTileCap = CAP;
     static_assert(CAP % 4 == 0, "the value area behind key0/pos0 must stay 8-byte aligned");
     static_assert(sizeof(T) <= 8, "values alias 8 bytes per entry");
+    static constexpr bool kWide = sizeof(T) == 8;   // f64 values need the 2 padding bytes per entry, f32 values fit an idle key buffer
+    static constexpr uint32_t kHashWords = kWide ? (uint32_t)CAP * 5u / 2u : (uint32_t)CAP * 2u;   // words behind key0
     uint32_t key0[CAP];
     uint16_t pos0[CAP];
-    uint16_t pad[CAP];
+    uint16_t pad[kWide ? CAP : 4];
     uint32_t key1[CAP];
     uint16_t pos1[CAP];
     union {
@@ -673,7 +688,9 @@ struct alignas(8) MergeSmem {
     __device__ __forceinline__ uint32_t *key(int c) { return c ? key1 : key0; }
     __device__ __forceinline__ uint16_t *pos(int c) { return c ? pos1 : pos0; }
     // where the values go once the sorted keys sit in buffer `c`
-    __device__ __forceinline__ T *vals(int c) { return reinterpret_cast<T *>(c ? reinterpret_cast<char *>(key0) : reinterpret_cast<char *>(pad)); }
+    __device__ __forceinline__ T *vals(int c) {
+        return reinterpret_cast<T *>(c ? reinterpret_cast<char *>(key0) : kWide ? reinterpret_cast<char *>(pad) : reinterpret_cast<char *>(key1));
+    }
     __device__ __forceinline__ uint32_t *htab() { return reinterpret_cast<uint32_t *>(pos0); }
     // long runs: the part of the dead digit counters that `rank` leaves free
     static constexpr int kMaxLong = CAP / kRunShort;
@@ -1041,7 +1058,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
         // the sort to deliver it makes successors stall behind slower predecessors (measured: +27 %); a hash set
         // over the keys gives the same number right after staging.  The table lives in LDS that is idle until the
         // first sort pass (everything behind key0: exactly 2.5 words per entry).
-        constexpr uint32_t HS = (uint32_t)kTileCap * 5u / 2u;
+        constexpr uint32_t HS = MergeSmem<T, NT, CAP>::kHashWords;
         uint32_t *htab = sm.htab();
         constexpr bool INPLACE = (ABL & 32) != 0;
         const bool early = nbits > 0 && keybits < 32 && !(ABL & 2) && !(ABL & 8) && !INPLACE;
