@@ -4,13 +4,16 @@
 //   symbolic   every non-zero A[i,k] owns one CHUNK of nnz(B[k,:]) partial products; chunks of one
 //              output row are laid out contiguously, ordered by k, so a row's partial products are
 //              one contiguous span of the staging buffer and the row id is implicit.
+//   plan       (osp_split.h) rows longer than one merge tile: their column ranges and, for every chunk
+//              and range, where the chunk's run goes -- so that the multiply can write such a row
+//              range by range ("direct" rows) instead of a split pass moving it afterwards.
 //   multiply   cscMulcsr (SimSpGEMM.cpp:265-281): column k of A x row k of B, written chunk by
-//              chunk.  The product space is flattened and cut into equal slices, one per wave.
-//   merge      deduplicateCOO (SimSpGEMM.cpp:519-535): per tile of consecutive rows, a stable LSD
-//              radix sort on (row, col) in LDS, equal keys summed in staging order (= ascending
-//              k, the order the oracle's stable sort yields), result written back in place.
-//              Rows too long for LDS take the global-sort path.
-//   compact    per-row results -> final CSR at exact offsets.
+//              chunk (or run by run).  The product space is flattened and cut into equal slices,
+//              one per wave.
+//   merge      deduplicateCOO (SimSpGEMM.cpp:519-535): per tile of consecutive rows -- or ranges of one
+//              long row --, a stable LSD radix sort on (row, col) in LDS, equal keys summed in staging
+//              order (= ascending k, the order the oracle's stable sort yields), every tile placed in
+//              the final CSR by a decoupled look-back: merged rows are written once.
 #pragma once
 #include <type_traits>
 #include "osp_prims.h"

@@ -1,15 +1,20 @@
-// osp_split.h -- long rows: one stable MSD split by column range, so that the LDS tile kernel can
-// merge them too.
+// osp_split.h -- long rows: by column range, so that the LDS tile kernel can merge them too.
 //
 // A row whose partial products exceed one LDS tile (thousands of chunks' worth in skewed matrices)
-// is cut into 2^b column ranges ("segments"): one segmented, stable counting-sort pass on the top b
-// bits of the column moves its entries from the staging buffer into a second buffer, segment by
-// segment.  Inside a segment the staging order (ascending k) is preserved, so the merge still sums
-// equal keys in the oracle's order.  The segments then look like short rows: the ordinary tile
-// planner packs them and merge_tiles_kernel merges them; concatenated in segment order they are the
-// row's sorted result.  (Reference for the operation being implemented: deduplicateCOO,
-// SimSpGEMM.cpp:519-535.  The reference simply sorts everything; there is no counterpart of this
-// file.)
+// reaches the tile kernel cut into column ranges ("segments") in a second buffer; inside a segment
+// the staging order (ascending k) is preserved, so the merge still sums equal keys in the oracle's
+// order.  The segments then look like short rows: the ordinary tile planner packs them and
+// merge_tiles_kernel merges them; concatenated in segment order they are the row's sorted result.
+// Three ways there (split_params_kernel decides per row):
+//   direct   the multiply phase writes the row range by range itself, following a plan made before it
+//            (direct_plan_kernel: exact histogram of the row's columns, ranges of at most one tile,
+//            one cell per chunk and range) -- no pass over the row's records at all;
+//   split    one workgroup moves the row with ONE stable segmented counting-sort pass on the top b
+//            bits of the column (split_row_kernel; rows without a chunk table: the parts-merging
+//            entry points, or OSP_DIRECT=0);
+//   stretch  rows too long for one workgroup: one workgroup per stretch, device-wide scan.
+// (Reference for the operation being implemented: deduplicateCOO, SimSpGEMM.cpp:519-535.  The
+// reference simply sorts everything; there is no counterpart of this file.)
 #pragma once
 #include "osp_kernels.h"
 

@@ -165,3 +165,36 @@ def test_integration_doc_quotes_the_compiled_binding():
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "all"], check=True, stdout=subprocess.DEVNULL)
         for sfx in ("f32", "f64"):
             assert os.path.exists(os.path.join(ROOT, "oracle", "_ref", f"binding_demo_{sfx}"))
+
+
+@pytest.mark.parametrize("threads", ["1", "3", "8"])
+def test_parallel_reader_gives_the_single_threaded_result(tmp_path, monkeypatch, port, threads):
+    """osp_mtx_read parses the lines behind the header on several threads (byte ranges cut at line starts) and concatenates
+    the pieces in file order: whatever the thread count, the result is what the oracle's one-pass readcoo gives -- comment and
+    blank lines in the middle, pattern entries, CRLF ends, no newline at the end of the file, fewer lines than threads."""
+    rng = np.random.default_rng(12)
+    lines = ["%%MatrixMarket matrix coordinate real general", "% a comment", "", "300 200 9999"]
+    for i in range(5000):
+        r, c = int(rng.integers(1, 301)), int(rng.integers(1, 201))
+        kind = i % 11
+        if kind == 0:
+            lines.append(f"{r} {c}")                      # pattern entry: value 1.0 (SimSpGEMM.cpp:92-93)
+        elif kind == 1:
+            lines.append(f"  {r}\t{c}   {rng.uniform(-3, 3):.17g}\r")   # blanks, a tab, CRLF
+        else:
+            lines.append(f"{r} {c} {rng.uniform(-3, 3):.9g}")
+        if i % 97 == 0:
+            lines.append("% comment in the middle")
+        if i % 131 == 0:
+            lines.append("   ")
+    big = tmp_path / "big.mtx"
+    big.write_text("\n".join(lines))                      # no newline at the end
+    small = tmp_path / "small.mtx"
+    small.write_text("%%MatrixMarket matrix coordinate real general\n4 4 2\n1 2 0.5\n4 4 -1e3")
+    monkeypatch.setenv("OSP_PARSE_THREADS", threads)
+    for path in (big, small):
+        got = S.read_mtx(str(path))
+        want = port.readcoo(str(path))
+        assert got[:2] == want[:2]
+        for x, y in zip(got[2:], want[2:]):
+            assert np.array_equal(x, y)
