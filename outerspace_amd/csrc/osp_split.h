@@ -64,7 +64,10 @@ constexpr uint64_t kSplitRowMax = (uint64_t)kSplitTarget << kSplitRowBits;  // l
 //   kModeDirect    the multiply phase writes it into the second buffer range by range (direct_plan_kernel + store_direct,
 //                  osp_kernels.h): no pass over its records at all
 constexpr uint8_t kModeSplitRow = 0, kModeStretch = 1, kModeDirect = 2;
-constexpr int kDirectThreads = 256;
+#ifndef OSP_DIRECT_THREADS
+#define OSP_DIRECT_THREADS 256
+#endif
+constexpr int kDirectThreads = OSP_DIRECT_THREADS;
 constexpr int kDirectCells = 4096;     // LDS words of direct_plan_kernel's (chunk, range) cells: counts and in-chunk starts
 constexpr int kDirectMaxRanges = 255;  // ranges per direct row (a byte per fine bin names the range)
 constexpr uint64_t kDirectRowCells = 1ull << 19;  // (chunk, range) cells of ONE direct row at most
@@ -598,7 +601,13 @@ __device__ __forceinline__ bool wave_run_head(uint32_t key, bool valid, uint32_t
 #ifndef OSP_DIRECT_UNR
 #define OSP_DIRECT_UNR 8
 #endif
-constexpr int kDirectChunkBlock = 512;    // chunks of a row whose descriptors sit in LDS at a time
+#ifndef OSP_DIRECT_CHUNK_BLOCK
+#define OSP_DIRECT_CHUNK_BLOCK 512
+#endif
+#ifndef OSP_DIRECT_CELLS_LDS
+#define OSP_DIRECT_CELLS_LDS 1024
+#endif
+constexpr int kDirectChunkBlock = OSP_DIRECT_CHUNK_BLOCK;    // chunks of a row whose descriptors sit in LDS at a time
 // first index c in [0, n) with cst[c + 1] > i   (cst ascending, cst[n] > i)
 __device__ __forceinline__ uint32_t direct_find_chunk(const uint32_t *cst, uint32_t n, uint32_t i) {
     uint32_t lo = 0, hi = n;
@@ -623,7 +632,7 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
     const uint32_t *__restrict__ perm, const uint32_t *__restrict__ b_colidx, uint64_t *__restrict__ vrow_off,
     uint32_t *__restrict__ vcol0, uint32_t *__restrict__ vcol1, uint32_t *__restrict__ cells, uint64_t *__restrict__ chunk_off) {
     constexpr int NT = kDirectThreads, NFINE = 1 << kSplitRowBits, CBL = kDirectChunkBlock, UNR = OSP_DIRECT_UNR;
-    constexpr int kCellsLds = kDirectCells / 4;
+    constexpr int kCellsLds = OSP_DIRECT_CELLS_LDS;
     __shared__ uint32_t hist[NFINE + 1];     // bin counts, then their exclusive prefix
     __shared__ uint16_t nxt[NFINE];          // first bin of the range that follows a range starting at this bin
     __shared__ uint8_t lut[NFINE];
@@ -708,11 +717,15 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
     // ---- 2. greedy grouping into ranges of at most `cap`: prefix sums, the bin every range starting at d ends before,
     // then one thread follows that chain (a few steps instead of one per bin)
     {
-        const uint32_t v0 = 2 * tid < nfine ? hist[2 * tid] : 0u, v1 = 2 * tid + 1 < nfine ? hist[2 * tid + 1] : 0u;
+        constexpr int PER = NFINE / NT;   // bins per thread (blocked)
+        static_assert(NFINE % NT == 0 && PER >= 1, "the fine bins are scanned PER per thread");
+        uint32_t v[PER], sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; q++) { const uint32_t d = tid * PER + q; v[q] = d < nfine ? hist[d] : 0u; sum += v[q]; }
         uint32_t total;
-        const uint32_t ex = block_excl_scan<uint32_t, NT>(v0 + v1, scratch, &total);
-        if (2 * tid < nfine) hist[2 * tid] = ex;
-        if (2 * tid + 1 < nfine) hist[2 * tid + 1] = ex + v0;
+        uint32_t ex = block_excl_scan<uint32_t, NT>(sum, scratch, &total);
+#pragma unroll
+        for (int q = 0; q < PER; q++) { const uint32_t d = tid * PER + q; if (d < nfine) hist[d] = ex; ex += v[q]; }
         if (tid == 0) hist[nfine] = total;
     }
     __syncthreads();
@@ -751,7 +764,7 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
     // ---- 3. cells, a block of chunks at a time
     const uint32_t CB = max(1u, min((uint32_t)CBL, (uint32_t)kCellsLds / T));
     // column prefixes by (group of chunks, range): G groups of S chunks each
-    const uint32_t G = max(1u, min((uint32_t)NT / T, 16u));
+    const uint32_t G = max(1u, min((uint32_t)NT / T, 16u));   // (T > NT: one group, the ranges in rounds of NT)
     for (uint32_t cb = 0; cb < nc; cb += CB) {
         const uint32_t nb = min(CB, nc - cb);
         for (uint32_t x = tid; x < nb * T; x += NT) cellm[x] = 0;
@@ -772,27 +785,31 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
             uint32_t run = 0;
             for (uint32_t t = 0; t < T; t++) { lsm[cl * T + t] = run; run += cellm[cl * T + t]; }
         }
-        // where every chunk's run starts inside its range: sums per group of chunks, then the walk
+        // where every chunk's run starts inside its range: sums per group of chunks, then the walk (NT ranges at a time)
         const uint32_t S = (nb + G - 1) / G;
-        const uint32_t g = tid / T, t = tid - g * T;
-        const bool on = g < G;
-        uint32_t run0 = 0;
-        if (on) {
-            uint32_t sum = 0;
-            for (uint32_t cl = g * S; cl < min(nb, (g + 1) * S); cl++) sum += cellm[cl * T + t];
-            psum[tid] = sum;
-            run0 = cursor[t];   // read before the barrier: the last group rewrites it behind it
-        }
-        __syncthreads();
-        if (on) {
-            uint32_t run = run0;
-            for (uint32_t gg = 0; gg < g; gg++) run += psum[gg * T + t];
-            const uint32_t rbase = q0 + roff[t];
-            for (uint32_t cl = g * S; cl < min(nb, (g + 1) * S); cl++) {
-                rb[lutw + (uint64_t)(cb + cl) * Ta + t] = rbase + run - lsm[cl * T + t];
-                run += cellm[cl * T + t];
+        for (uint32_t t0 = 0; t0 < T; t0 += NT) {
+            const uint32_t Tb = min((uint32_t)NT, T - t0);   // ranges of this round; G groups fit when T <= NT (else G = 1)
+            const uint32_t g = tid / Tb, t = t0 + (tid - g * Tb);
+            const bool on = g < G;
+            uint32_t run0 = 0;
+            __syncthreads();   // psum of the previous round has been read
+            if (on) {
+                uint32_t sum = 0;
+                for (uint32_t cl = g * S; cl < min(nb, (g + 1) * S); cl++) sum += cellm[cl * T + t];
+                psum[tid] = sum;
+                run0 = cursor[t];   // read before the barrier: the last group rewrites it behind it
             }
-            if (g == G - 1) cursor[t] = run;   // (the last group ends at the block's end, possibly with no chunk of its own)
+            __syncthreads();
+            if (on) {
+                uint32_t run = run0;
+                for (uint32_t gg = 0; gg < g; gg++) run += psum[gg * Tb + (t - t0)];
+                const uint32_t rbase = q0 + roff[t];
+                for (uint32_t cl = g * S; cl < min(nb, (g + 1) * S); cl++) {
+                    rb[lutw + (uint64_t)(cb + cl) * Ta + t] = rbase + run - lsm[cl * T + t];
+                    run += cellm[cl * T + t];
+                }
+                if (g == G - 1) cursor[t] = run;   // (the last group ends at the block's end, possibly with no chunk of its own)
+            }
         }
         for (uint32_t cl = tid; cl < nb; cl += NT)
             chunk_off[perm[c0 + cb + cl]] = direct_desc((uint32_t)cellbase[h], lutw + (cb + cl) * Ta, (uint32_t)sh);
