@@ -467,6 +467,7 @@ template <class T> struct MergeIO {
     int64_t *c_rowptr; uint32_t *c_col; T *c_val;  // output (c_rowptr indexed by absolute row id)
     const uint64_t *out_in; uint64_t *out_out;    // entries written before / after this call (device)
     ChunkTable<T> ct{};                           // row-wise variant: rows that fit a tile are computed in the tile kernel
+    uint32_t *abort_word = nullptr;               // set by a look-back that gave up (merge_tiles_kernel): the product is an error
 };
 
 struct TilePlan {
@@ -815,9 +816,13 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
                                                                            nullptr, 0u, nullptr, nullptr, nullptr, desc);
     }
     uint64_t *tile_status = sc.get<uint64_t>(ntot);
-    uint32_t *ticket = sc.get<uint32_t>(1);
+    // ticket counters: one word, or OSP_MERGE_SHARDS of them plus the arrival counter (osp_kernels.h, take_ticket; measured:
+    // no gain while the look-back is on -- the chain and the hash count bound the kernel, not the word -- so the default is 1)
+    static const uint32_t want_shards = getenv("OSP_MERGE_SHARDS") ? std::min(std::max(atoi(getenv("OSP_MERGE_SHARDS")), 1), 16) : 1;
+    const uint32_t nshards = ntot >= 1024 ? want_shards : 1u;
+    uint32_t *ticket = sc.get<uint32_t>((uint64_t)(nshards + 1) * kTicketStride);
     OSP_HIP(hipMemsetAsync(tile_status, 0, (uint64_t)ntot * sizeof(uint64_t), s));
-    OSP_HIP(hipMemsetAsync(ticket, 0, sizeof(uint32_t), s));
+    OSP_HIP(hipMemsetAsync(ticket, 0, (uint64_t)(nshards + 1) * kTicketStride * sizeof(uint32_t), s));
     dbg_sync(s, "tile planning, splits, over-long segments");
     tm.begin(PH_MERGE_K);
     // persistent workgroups: as many as the LDS lets run at once
@@ -825,12 +830,12 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         const uint32_t rw_grid = ctx->cus * (uint32_t)merge_wgs_per_cu<T, kMergeThreads, TileCap<T>::value, kMergeMaxWgs, 64>();
         OSP_WITH_RA(ctx, merge_tiles_kernel<T, kMergeThreads, 64, TileCap<T>::value, kMergeMaxWgs, RA>
                     <<<std::min<uint32_t>(ntot, rw_grid), kMergeThreads, 0, s>>>(desc, ntot, lv, colbits, tile_status, ticket, io.out_in, io.c_col,
-                                                                                 io.c_val, io.out_out, io.ct));
+                                                                                 io.c_val, io.out_out, io.ct, nshards, io.abort_word));
     } else {
         const uint32_t merge_grid = ctx->cus * (uint32_t)merge_wgs_per_cu<T, kMergeThreads, TileCap<T>::value>();
         OSP_WITH_RA(ctx, merge_tiles_kernel<T, kMergeThreads, 0, TileCap<T>::value, kMergeMaxWgs, RA>
                     <<<std::min<uint32_t>(ntot, merge_grid), kMergeThreads, 0, s>>>(desc, ntot, lv, colbits, tile_status, ticket, io.out_in, io.c_col,
-                                                                                    io.c_val, io.out_out));
+                                                                                    io.c_val, io.out_out, ChunkTable<T>{}, nshards, io.abort_word));
     }
     tm.end(PH_MERGE_K);
     dbg_sync(s, "merge tiles");
@@ -963,6 +968,12 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     Part<T> *stage = sc.get<Part<T>>(max_panel);
     uint64_t *out_nnz = sc.get<uint64_t>((uint64_t)npanels + 1);  // nnz written before panel p
     OSP_HIP(hipMemsetAsync(out_nnz, 0, sizeof(uint64_t), s));
+    uint32_t *abort_word = sc.get<uint32_t>(1);   // raised by a tile whose predecessors never published (merge_tiles_kernel's watchdog)
+    OSP_HIP(hipMemsetAsync(abort_word, 0, sizeof(uint32_t), s));
+    auto check_abort = [&](uint32_t flag) {
+        if (flag) throw Error(OSP_ERR_HIP, "the merge made no progress for seconds (a tile's predecessors never published their sizes); "
+                                           "with OSP_MERGE_SHARDS > 1 that happens when fewer workgroups than shards ever run side by side");
+    };
     if (sink) {
         // ---- streaming: one output buffer sized for the largest panel's bound, reused by every panel ----
         std::vector<uint64_t> h_ub(npanels + 1);
@@ -989,9 +1000,13 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
             OSP_HIP(hipMemsetAsync(cells, 0, 2 * sizeof(uint64_t), s));
             MergeIO<T> io{stage, d_row_off, r0, r1, base, prow - r0, c_col, c_val, cells, cells + 1};
             if (ct) io.ct = *ct;
+            io.abort_word = abort_word;
             merge_panel<T>(ctx, res, tm, io, colbits, plan);
             tm.end(PH_MERGE);
-            const uint64_t nnz_p = d2h(cells + 1, s);  // synchronises: the panel is complete
+            uint64_t nnz_p = 0;
+            uint32_t aflag = 0;
+            { Gather g(s); g.add(&nnz_p, (const uint64_t *)cells + 1); g.add(&aflag, (const uint32_t *)abort_word); g.wait(); }  // synchronises: the panel is complete
+            check_abort(aflag);
             nnz_total += nnz_p;
             const osp_panel_t pd{r0, r1, nnz_p, prow, c_col, c_val, p, npanels, {0, 0}};
             ctx->ensure_free(2ull << 30);  // the consumer needs room of its own
@@ -1018,10 +1033,14 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         tm.begin(PH_MERGE);
         MergeIO<T> io{stage, d_row_off, r0, r1, base, res->rowptr - r_lo, c_col, c_val, out_nnz + p, out_nnz + p + 1};
         if (ct) io.ct = *ct;
+        io.abort_word = abort_word;
         merge_panel<T>(ctx, res, tm, io, colbits, plan);
         tm.end(PH_MERGE);
     }
-    const uint64_t nnz_total = d2h(out_nnz + npanels, s);
+    uint64_t nnz_total = 0;
+    uint32_t aflag = 0;
+    { Gather g(s); g.add(&nnz_total, (const uint64_t *)out_nnz + npanels); g.add(&aflag, (const uint32_t *)abort_word); g.wait(); }
+    check_abort(aflag);
     res->info.nnz_c = nnz_total;
     // give memory back when the product compressed a lot (copy is small next to the P-sized work)
     if (Context::bucket(std::max<uint64_t>(nnz_total, 1) * sizeof(T)) * 10 < Context::bucket(std::max<uint64_t>(cap_c, 1) * sizeof(T)) * 7) {

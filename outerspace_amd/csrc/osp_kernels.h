@@ -775,12 +775,37 @@ constexpr int kLookWin = 1;
 __device__ __forceinline__ void lookback_publish(uint64_t *status, uint32_t t, uint64_t total) {
     __hip_atomic_store(&status[t], (t == 0 ? kStatusPrefix : kStatusAgg) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Tickets in SHARDS (merge_tiles_kernel, nshards > 1).  One counter word serves ~88 returning atomics per microsecond
+// whoever asks, and the tile kernel asks for one per tile: with the look-back and the hash count switched off the kernel
+// still takes 2.19 ms for 174 763 tiles, against 1.76 ms with tiles assigned statically (tools/bench_merge).  With S shards,
+// tile t belongs to shard t mod S and every shard hands out ITS tiles in ascending order from a counter of its own (one
+// 128-byte line each).  A workgroup joins the shard its ARRIVAL number selects (one atomic per workgroup on a further
+// word: the workgroups that are running cover the shards round-robin in the order they started, whatever the dispatcher
+// does) and moves on to the next shard when its own is exhausted.
+// What it keeps of the single counter's guarantee -- a tile only waits for tiles that running workgroups hold -- : the
+// smallest unfinished tile is the next ticket of its shard, so some workgroup of that shard that is running (or starts)
+// takes it; that needs at least S workgroups of the launch to get to run side by side at some time, where the single
+// counter needs one.  The look-back therefore gives up after kLookbackSpinLimit fruitless rounds (seconds), raises the
+// product's abort word, and the host reports an error instead of a hang; OSP_MERGE_SHARDS=1 is the single counter.
+constexpr int kTicketStride = 32;                    // 32-bit words between two shard counters
+constexpr uint32_t kLookbackSpinLimit = 1u << 22;
+__device__ __forceinline__ uint32_t take_ticket(uint32_t *ticket, uint32_t nshards, uint32_t &shard, uint32_t ntiles) {
+    if (nshards <= 1) return atomicAdd(ticket, 1u);
+    for (uint32_t tries = 0; tries < nshards; tries++) {
+        const uint32_t n = atomicAdd(&ticket[shard * kTicketStride], 1u);
+        const uint64_t t = (uint64_t)n * nshards + shard;
+        if (t < ntiles) return (uint32_t)t;
+        shard = shard + 1 == nshards ? 0u : shard + 1;   // this shard's tiles are gone: help the next one
+    }
+    return ntiles;
+}
 template <bool PUBLISH = true>
-__device__ __forceinline__ uint64_t lookback_prefix(uint64_t *status, uint32_t t, uint64_t total) {
+__device__ __forceinline__ uint64_t lookback_prefix(uint64_t *status, uint32_t t, uint64_t total, uint32_t *abort_word = nullptr) {
     const unsigned lane = lane_id();
     if (PUBLISH && lane == 0) lookback_publish(status, t, total);
     uint64_t excl = 0;
     int64_t b = (int64_t)t - 1;
+    uint32_t spins = 0;
     while (b >= 0) {
         uint64_t sv[kLookWin];
 #pragma unroll
@@ -805,7 +830,16 @@ __device__ __forceinline__ uint64_t lookback_prefix(uint64_t *status, uint32_t t
                 }
             }
         }
-        if (retry) { __builtin_amdgcn_s_sleep(1); continue; }  // keep what is already summed? no: re-read all
+        if (retry) {
+            __builtin_amdgcn_s_sleep(1);
+            if (abort_word && (++spins & 255u) == 0) {   // (wave-uniform)
+                // nobody is going to publish what this tile waits for, or somebody else found that out: stop waiting (the
+                // partial prefix keeps every write inside the output; the host turns the word into an error)
+                if (spins >= kLookbackSpinLimit && lane == 0) atomicExch(abort_word, 1u);
+                if (spins >= kLookbackSpinLimit || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            }
+            continue;  // keep what is already summed? no: re-read all
+        }
         excl += wave_reduce_sum_u62(part);
         if (done) break;
         b -= (int64_t)kLookWin * kWave;
@@ -958,7 +992,7 @@ template <class T, int NT, int ABL = 0, int CAP = TileCap<T>::value, int MAXWG =
 __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>())) void merge_tiles_kernel(
     const TileDesc *__restrict__ desc, uint32_t ntiles, const MergeLevels<T> lvl, int colbits, uint64_t *tile_status,
     uint32_t *ticket, const uint64_t *__restrict__ out_base_p, uint32_t *__restrict__ c_col, T *__restrict__ c_val,
-    uint64_t *__restrict__ out_end_p, const ChunkTable<T> ct = ChunkTable<T>{}) {
+    uint64_t *__restrict__ out_end_p, const ChunkTable<T> ct = ChunkTable<T>{}, uint32_t nshards = 1, uint32_t *abort_word = nullptr) {
     __shared__ MergeSmem<T, NT, CAP> sm;
     __shared__ TileDesc s_dnext;
     __shared__ uint32_t s_tnext;
@@ -974,8 +1008,10 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
     constexpr int DPT = (kDigits + NT - 1) / NT;  // digits per thread in the scan step
     static_assert(kTileMaxRows + 1 <= NT, "row offsets are fetched one per thread");
     const unsigned tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    uint32_t shard = 0;   // (thread 0's copy is the one in use: it takes every ticket of the workgroup)
     if (tid == 0) {
-        const uint32_t t0 = (ABL & 4) ? blockIdx.x : atomicAdd(ticket, 1u);
+        if (nshards > 1) shard = atomicAdd(&ticket[nshards * kTicketStride], 1u) % nshards;   // by arrival, see take_ticket
+        const uint32_t t0 = (ABL & 4) ? blockIdx.x : take_ticket(ticket, nshards, shard, ntiles);
         s_tnext = t0;
         if (t0 < ntiles) s_dnext = desc[t0];
     }
@@ -1035,9 +1071,9 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
             // offset chain; heavy_copy_kernel moves its entries once c_rowptr is known
             if (w == 0) {
                 const uint64_t total = lvl.heavy_nnz[d.lvl][ra];
-                const uint64_t excl = (ABL & 2) ? (uint64_t)t * kTileCap : lookback_prefix(tile_status, t, total);
+                const uint64_t excl = (ABL & 2) ? (uint64_t)t * kTileCap : lookback_prefix(tile_status, t, total, abort_word);
                 if (lane == 0) {
-                    tn_reg = (ABL & 4) ? t + gridDim.x : atomicAdd(ticket, 1u);
+                    tn_reg = (ABL & 4) ? t + gridDim.x : take_ticket(ticket, nshards, shard, ntiles);
                     c_rowptr[ra] = (int64_t)(out_base + excl);
                     if (t + 1 == ntiles) *out_end_p = out_base + excl + total;
                     s_tnext = tn_reg;
@@ -1389,11 +1425,11 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
         if (w == 0) {
             const uint64_t excl = INPLACE   ? 0ull
                                  : (ABL & 2) ? (uint64_t)t * kTileCap
-                                 : early     ? lookback_prefix<false>(tile_status, t, total)  // count already published
-                                             : lookback_prefix<true>(tile_status, t, total);
+                                 : early     ? lookback_prefix<false>(tile_status, t, total, abort_word)  // count already published
+                                             : lookback_prefix<true>(tile_status, t, total, abort_word);
             if (lane == 0) {
                 sm.excl = excl;
-                tn_reg = (ABL & 4) ? t + gridDim.x : atomicAdd(ticket, 1u);
+                tn_reg = (ABL & 4) ? t + gridDim.x : take_ticket(ticket, nshards, shard, ntiles);
             }
         }
         OSP_PROF_MARK(7);

@@ -83,25 +83,39 @@ __global__ void tiles_kernel(uint32_t *tile_rows, uint32_t ntiles, uint32_t rpt)
 }
 
 TileDesc *g_desc; uint32_t g_grid = 512;
+uint32_t g_shards = 1;
+template <int NT, int ABL, int CAP, int MAXWG, int SHARDS>
+float run_sharded(uint32_t *tile_rows, uint32_t ntiles, uint64_t M, uint64_t *row_off, uint32_t *pcol, double *pval,
+          uint32_t *heavy, uint64_t *status, uint32_t *ticket, uint64_t *outn, int64_t *rowptr, uint32_t *ccol, double *cval);
 template <int NT, int ABL, int CAP = 2 * NT * 3, int MAXWG = 5>
 float run(uint32_t *tile_rows, uint32_t ntiles, uint64_t M, uint64_t *row_off, uint32_t *pcol, double *pval,
           uint32_t *heavy, uint64_t *status, uint32_t *ticket, uint64_t *outn, int64_t *rowptr, uint32_t *ccol, double *cval) {
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     CK(hipMemsetAsync(status, 0, (uint64_t)ntiles * 8, 0));
-    CK(hipMemsetAsync(ticket, 0, sizeof(uint32_t), 0));
+    CK(hipMemsetAsync(ticket, 0, 64 * kTicketStride * sizeof(uint32_t), 0));
     CK(hipMemsetAsync(outn, 0, 16, 0));
     CK(hipEventRecord(a, 0));
     MergeLevels<double> lv{};
     lv.stage[0] = g_stage; lv.row_off[0] = row_off; lv.base[0] = 0; lv.c_rowptr[0] = rowptr; lv.heavy_nnz[0] = heavy;
     const uint32_t grid = g_grid * (uint32_t)merge_wgs_per_cu<double, NT, CAP, MAXWG>() / 2;  // g_grid assumes 2 per CU
     merge_tiles_kernel<double, NT, ABL, CAP, MAXWG><<<ntiles < grid ? ntiles : grid, NT, 0, 0>>>(g_desc, ntiles, lv, 22, status, ticket, outn,
-                                                                                         ccol, cval, outn + 1);
+                                                                                         ccol, cval, outn + 1, ChunkTable<double>{}, g_shards,
+                                                                                         ticket + 40 * kTicketStride);
     CK(hipEventRecord(b, 0));
     CK(hipEventSynchronize(b));
     float ms;
     CK(hipEventElapsedTime(&ms, a, b));
     CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
+    return ms;
+}
+
+template <int NT, int ABL, int CAP, int MAXWG, int SHARDS>
+float run_sharded(uint32_t *tile_rows, uint32_t ntiles, uint64_t M, uint64_t *row_off, uint32_t *pcol, double *pval,
+          uint32_t *heavy, uint64_t *status, uint32_t *ticket, uint64_t *outn, int64_t *rowptr, uint32_t *ccol, double *cval) {
+    g_shards = SHARDS;
+    const float ms = run<NT, ABL, CAP, MAXWG>(tile_rows, ntiles, M, row_off, pcol, pval, heavy, status, ticket, outn, rowptr, ccol, cval);
+    g_shards = 1;
     return ms;
 }
 
@@ -124,7 +138,7 @@ int main(int argc, char **argv) {
     uint32_t *pcol, *tile_rows, *heavy, *ticket, *ccol; double *pval, *cval; uint64_t *row_off, *status, *outn; int64_t *rowptr;
     CK(hipMalloc(&pcol, P * 4)); CK(hipMalloc(&pval, P * 8)); CK(hipMalloc(&ccol, (P + 4096ull * 0) * 4 + (uint64_t)ntiles * 3072 * 4));
     CK(hipMalloc(&cval, (uint64_t)ntiles * 3072 * 8 + P * 8)); CK(hipMalloc(&row_off, (M + 1) * 8)); CK(hipMalloc(&tile_rows, ntiles * 4));
-    CK(hipMalloc(&heavy, M * 4)); CK(hipMalloc(&status, (uint64_t)ntiles * 8)); CK(hipMalloc(&ticket, sizeof(uint32_t))); CK(hipMalloc(&outn, 16));
+    CK(hipMalloc(&heavy, M * 4)); CK(hipMalloc(&status, (uint64_t)ntiles * 8)); CK(hipMalloc(&ticket, 64 * kTicketStride * sizeof(uint32_t))); CK(hipMalloc(&outn, 16));
     CK(hipMalloc(&rowptr, (M + 1) * 8));
     const uint32_t clen = argc > 4 ? atoi(argv[4]) : 16;
     fill_kernel<<<(unsigned)((P + 255) / 256), 256>>>(pcol, pval, P);
@@ -150,6 +164,9 @@ int main(int argc, char **argv) {
     std::vector<V> vs = {
         {"radix NT256 cap1536 full", 1536, run<256, 0, 1536>}, {"radix NT256 cap1536 nosort", 1536, run<256, 1, 1536>},
         {"radix NT256 cap1536 nolb", 1536, run<256, 2, 1536>}, {"radix NT256 cap1536 nosort+nolb", 1536, run<256, 3, 1536>},
+        {"radix NT256 cap1536 full 8 shards", 1536, run_sharded<256, 0, 1536, 5, 8>}, {"radix NT256 cap1536 full 4 shards", 1536, run_sharded<256, 0, 1536, 5, 4>},
+        {"radix NT256 cap1536 full 16 shards", 1536, run_sharded<256, 0, 1536, 5, 16>}, {"radix NT256 cap1536 full 2 shards", 1536, run_sharded<256, 0, 1536, 5, 2>},
+        {"radix NT256 cap1536 nolb 8 shards", 1536, run_sharded<256, 2, 1536, 5, 8>},
         {"radix NT256 cap1536 latecount", 1536, run<256, 8, 1536>},
         {"radix NT256 cap1536 static tiles (no ticket)", 1536, run<256, 4, 1536>},
         {"radix NT256 cap1536 static nolb", 1536, run<256, 6, 1536>}, {"radix NT256 cap1536 static nosort+nolb", 1536, run<256, 7, 1536>},
@@ -167,7 +184,9 @@ int main(int argc, char **argv) {
         unsigned long long ref = 0; uint64_t ref_total = 0;
         for (uint32_t g : {512u, 1u, 7u, 64u, 511u, 513u, 1000u, 4096u, 100000u}) {
             g_grid = g;
+            g_shards = getenv("SHARDS") ? atoi(getenv("SHARDS")) : 1;
             float ms = run<256, 0, 1536>(ARGS);
+            g_shards = 1;
             uint64_t h_out[2]; CK(hipMemcpy(h_out, outn, 16, hipMemcpyDeviceToHost));
             CK(hipMemset(d_sum, 0, 8));
             const uint64_t n = std::max<uint64_t>(M + 1, h_out[1]);
