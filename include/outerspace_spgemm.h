@@ -17,7 +17,9 @@
  *   CSRMatrix coo2csr<transpose>(coo, N)    SimSpGEMM.cpp:102-152  osp_coo_to_compressed_* (host), osp_spgemm_coo (GPU)
  *   dupcheck -> throw(233)                  SimSpGEMM.cpp:43-53    OSP_ERR_DUPLICATE (= 233)
  *   assert(csc.pos.size()==csr.pos.size())  SimSpGEMM.cpp:267,882  OSP_ERR_DIM
- *   main(argv[1]=A.mtx, argv[2]=B.mtx)      SimSpGEMM.cpp:819-894  osp_spgemm_mtx / tools/osp_spgemm
+ *   main(argv[1]=A.mtx, argv[2]=B.mtx)      SimSpGEMM.cpp:819-894  osp_spgemm_mtx / outerspace_amd/osp_spgemm
+ *   x = relu(fc(x)) between two layers      NN_models/models.py:17-31  osp_csr_bias_relu (+ osp_result_coo_rows: the next product's operand)
+ *   (nothing: one process, one thread)      SURVEY.md 8e          osp_multi_* -- the k-sharded product over the GPUs of a node
  *
  * Conventions: plain pointers and sizes only; no exceptions cross the ABI; every function
  * returns an osp_status_t (0 = ok); osp_last_error_string() describes the last failure on the
@@ -39,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OSP_VERSION 1
+#define OSP_VERSION 3   /* round of the build: 3 = osp_multi_*, osp_csr_bias_relu, osp_result_coo_rows, direct-row counters */
 
 typedef enum osp_status {
     OSP_OK = 0,
