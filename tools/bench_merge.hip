@@ -167,6 +167,7 @@ int main(int argc, char **argv) {
         {"radix NT256 cap1536 full 8 shards", 1536, run_sharded<256, 0, 1536, 5, 8>}, {"radix NT256 cap1536 full 4 shards", 1536, run_sharded<256, 0, 1536, 5, 4>},
         {"radix NT256 cap1536 full 16 shards", 1536, run_sharded<256, 0, 1536, 5, 16>}, {"radix NT256 cap1536 full 2 shards", 1536, run_sharded<256, 0, 1536, 5, 2>},
         {"radix NT256 cap1536 nolb 8 shards", 1536, run_sharded<256, 2, 1536, 5, 8>},
+        {"radix NT256 cap1536 latecount 8 shards", 1536, run_sharded<256, 8, 1536, 5, 8>},
         {"radix NT256 cap1536 latecount", 1536, run<256, 8, 1536>},
         {"radix NT256 cap1536 static tiles (no ticket)", 1536, run<256, 4, 1536>},
         {"radix NT256 cap1536 static nolb", 1536, run<256, 6, 1536>}, {"radix NT256 cap1536 static nosort+nolb", 1536, run<256, 7, 1536>},
