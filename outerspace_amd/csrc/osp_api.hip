@@ -351,6 +351,7 @@ struct Pinned {
     char *p = nullptr;     // two halves of `half` bytes each
     size_t half = 0;
     hipEvent_t done[2] = {nullptr, nullptr};  // the DMA out of / into half i has finished
+    uint64_t *collect = nullptr;              // device words a read-back of several scalars is gathered into (Gather)
     // (never freed: a thread_local destructor can run after the HIP runtime has shut down)
     void reserve(size_t want) {
         want = std::min(std::max<size_t>(want, 64), kStageChunk);
@@ -413,28 +414,45 @@ static void copy_d2h(void *dst, const void *src, size_t bytes, hipStream_t s) {
     OSP_HIP(hipEventSynchronize(pb.done[i ^ 1]));
     memcpy((char *)dst + off_prev, pb.p + (i ^ 1) * chunk, n_prev);
 }
-// several device scalars with ONE wait: a blocking read-back is a stream round trip, and a small product makes a dozen
+// several device scalars with ONE wait: a blocking read-back is a stream round trip, and a small product makes a dozen.
+// Three or more values are first gathered into consecutive device words by one tiny kernel and come back in ONE copy (a
+// copy of 8 bytes occupies the stream for 5-8 us: ten of them cost what the gather and its copy cost four times over).
+constexpr int kGatherMax = 24;
+struct GatherSrcs {
+    const void *p[kGatherMax];
+    uint8_t bytes[kGatherMax];
+};
+__global__ void gather_scalars_kernel(const GatherSrcs g, int n, uint64_t *out) {
+    const int i = threadIdx.x;
+    if (i < n) out[i] = g.bytes[i] == 8 ? *static_cast<const uint64_t *>(g.p[i]) : (uint64_t) * static_cast<const uint32_t *>(g.p[i]);
+}
 struct Gather {
     hipStream_t s;
-    char *pin;
-    size_t used = 0;
-    std::vector<std::pair<void *, std::pair<size_t, size_t>>> outs;  // host destination, (offset in the pinned buffer, bytes)
-    explicit Gather(hipStream_t st) : s(st) {
-        Pinned &pb = pinned_buffer();
-        pb.reserve(4096);
-        pin = pb.p;
-    }
+    Pinned &pb;
+    GatherSrcs srcs;
+    void *dst[kGatherMax];
+    int n = 0;
+    explicit Gather(hipStream_t st) : s(st), pb(pinned_buffer()) { pb.reserve(4096); }
     template <class T> void add(T *host_dst, const T *dptr) {
-        if (used + sizeof(T) > 4096) throw Error(OSP_ERR_ARG, "too many values in one read-back");
-        OSP_HIP(hipMemcpyAsync(pin + used, dptr, sizeof(T), hipMemcpyDeviceToHost, s));
-        outs.push_back({host_dst, {used, sizeof(T)}});
-        used += (sizeof(T) + 7) & ~size_t(7);
+        static_assert(sizeof(T) == 4 || sizeof(T) == 8, "read-backs are 32- or 64-bit scalars");
+        if (n == kGatherMax) throw Error(OSP_ERR_ARG, "too many values in one read-back");
+        srcs.p[n] = dptr;
+        srcs.bytes[n] = (uint8_t)sizeof(T);
+        dst[n++] = host_dst;
     }
     void wait() {
+        if (n == 0) return;
+        uint64_t *pin = reinterpret_cast<uint64_t *>(pb.p);
+        if (n >= 3) {
+            if (!pb.collect) OSP_HIP(hipMalloc((void **)&pb.collect, kGatherMax * sizeof(uint64_t)));
+            gather_scalars_kernel<<<1, kWave, 0, s>>>(srcs, n, pb.collect);
+            OSP_HIP(hipMemcpyAsync(pin, pb.collect, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        } else {
+            for (int i = 0; i < n; i++) OSP_HIP(hipMemcpyAsync(pin + i, srcs.p[i], srcs.bytes[i], hipMemcpyDeviceToHost, s));
+        }
         OSP_HIP(hipStreamSynchronize(s));
-        for (auto &o : outs) memcpy(o.first, pin + o.second.first, o.second.second);
-        outs.clear();
-        used = 0;
+        for (int i = 0; i < n; i++) memcpy(dst[i], pin + i, srcs.bytes[i]);   // (little endian: the low bytes of the word)
+        n = 0;
     }
 };
 template <class T> static T d2h(const T *dptr, hipStream_t s) {
@@ -478,23 +496,27 @@ struct TilePlan {
 };
 
 // Greedy tile packing (coarse blocks of ~8 tiles, one walker thread per block) + the list of long rows.
+// total: entries of rows [r0, r1); nforce: upper bound of the rows flagged in force_start -- what bounds the number of
+// coarse blocks on the host (the count itself is only read by the kernels).
 static TilePlan plan_tiles(Context *ctx, Scratch &sc, const uint64_t *row_off, uint64_t r0, uint64_t r1, uint64_t base,
-                           uint32_t cap, uint32_t max_rows, const uint8_t *force_start) {
+                           uint32_t cap, uint32_t max_rows, const uint8_t *force_start, uint64_t total, uint64_t nforce) {
     hipStream_t s = ctx->stream;
     const uint64_t nr = r1 - r0;
     TilePlan pl;
     uint32_t *flag_scan = sc.get<uint32_t>(nr + 1);
     uint32_t *tmp_rows = sc.get<uint32_t>(nr + 1);
     uint64_t *scan_tmp = sc.get<uint64_t>(scan_scratch_entries(std::max<uint64_t>(nr + 1, 16)));
-    CoarseStartFlag csf{row_off, r0, base, 8ull * cap, force_start};
+    const uint64_t slot = 8ull * cap;
+    CoarseStartFlag csf{row_off, r0, base, slot, force_start};
     device_exclusive_scan<CoarseStartFlag, uint32_t>(csf, nr, flag_scan, (uint32_t *)scan_tmp, s);
     compact_flagged_kernel<CoarseStartFlag><<<grid_for(nr, 256), 256, 0, s>>>(csf, flag_scan, nr, r0, tmp_rows);
-    const uint32_t ncb = d2h(flag_scan + nr, s);
+    // flagged: row 0, the forced rows, one row per slot boundary crossed, every 65536th row
+    const uint32_t ncb = (uint32_t)std::min<uint64_t>(nr, 2 + nforce + total / slot + nr / 65536);
+    const uint32_t *ncb_p = flag_scan + nr;
     uint32_t *cb_cnt = sc.get<uint32_t>((uint64_t)ncb + 1);
-    tile_walk_kernel<<<grid_for(ncb, 128), 128, 0, s>>>(tmp_rows, ncb, r1, row_off, cap, max_rows, nullptr, cb_cnt, nullptr);
+    tile_walk_kernel<<<grid_for(ncb, 128), 128, 0, s>>>(tmp_rows, ncb_p, ncb, r1, row_off, cap, max_rows, nullptr, cb_cnt, nullptr);
     device_exclusive_scan<LoadU32, uint32_t>(LoadU32{cb_cnt}, ncb, cb_cnt, (uint32_t *)scan_tmp, s);
-    // the long rows' list needs nothing of the tile list: its scan runs before the tile count is read back, and both
-    // counts come home with one wait
+    // the long rows' list needs nothing of the tile list: both counts come home with one wait
     HeavyRowFlag hrf{row_off, r0, cap};
     uint32_t *long_scan = sc.get<uint32_t>(nr + 1);
     uint32_t *long_tmp = sc.get<uint32_t>(scan_scratch_entries(std::max<uint64_t>(nr + 1, 16)));
@@ -503,7 +525,7 @@ static TilePlan plan_tiles(Context *ctx, Scratch &sc, const uint64_t *row_off, u
     compact_flagged_kernel<HeavyRowFlag><<<grid_for(nr, 256), 256, 0, s>>>(hrf, long_scan, nr, r0, pl.long_rows);
     { Gather g(s); g.add(&pl.ntiles, (const uint32_t *)cb_cnt + ncb); g.add(&pl.nlong, (const uint32_t *)long_scan + nr); g.wait(); }
     pl.tile_rows = sc.get<uint32_t>((uint64_t)pl.ntiles + 1);
-    tile_walk_kernel<<<grid_for(ncb, 128), 128, 0, s>>>(tmp_rows, ncb, r1, row_off, cap, max_rows, cb_cnt, nullptr, pl.tile_rows);
+    tile_walk_kernel<<<grid_for(ncb, 128), 128, 0, s>>>(tmp_rows, ncb_p, ncb, r1, row_off, cap, max_rows, cb_cnt, nullptr, pl.tile_rows);
     return pl;
 }
 
@@ -554,12 +576,12 @@ __global__ void mode_totals_kernel(const uint32_t *rows, uint32_t nlong, const u
 // and its segment tables -- and, for direct rows, the plan the multiply writes them by.
 template <class T>
 static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &pl, const uint64_t *row_off, uint64_t r0, uint64_t r1,
-                       uint64_t base, int colbits, const DirectSrc *ds) {
+                       uint64_t base, uint64_t count, int colbits, const DirectSrc *ds) {
     hipStream_t s = ctx->stream;
     Scratch &sc = pl.sc;
     constexpr uint32_t kCap = (uint32_t)TileCap<T>::value;
     pl.max_rows = (uint32_t)std::min<uint64_t>(kTileMaxRows, colbits >= 32 ? 1ull : (1ull << (32 - colbits)));
-    pl.p0 = plan_tiles(ctx, sc, row_off, r0, r1, base, kCap, pl.max_rows, nullptr);
+    pl.p0 = plan_tiles(ctx, sc, row_off, r0, r1, base, kCap, pl.max_rows, nullptr, count, 0);
     res->info.light_tiles += pl.p0.ntiles - pl.p0.nlong;
     if (!pl.p0.nlong) return;
     const uint32_t nlong = pl.p0.nlong;
@@ -707,7 +729,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         OSP_HIP(hipGetLastError());
         dbg_sync(s, "split: segment offsets");
         // ---- tiles over the segments; a tile never spans two long rows ----
-        p1 = plan_tiles(ctx, sc, vrow_off, 0, nvirt, 0, kCap, max_rows, vfirst);
+        p1 = plan_tiles(ctx, sc, vrow_off, 0, nvirt, 0, kCap, max_rows, vfirst, nh, nlong);
         dbg_sync(s, "tiles over the segments");
         vptr = (int64_t *)sc.get<uint64_t>(nvirt + 1);
         lv.stage[1] = qstage; lv.row_off[1] = vrow_off; lv.base[1] = 0; lv.c_rowptr[1] = vptr;
@@ -803,7 +825,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         chain_rows_kernel<<<grid_for(nlong + 1, 256), 256, 0, s>>>(p0.long_rows, nlong, p0.tile_rows, p0.ntiles, vbase, p1.tile_rows,
                                                                   p1.ntiles, j0, tb, extra);
         device_exclusive_scan<LoadU32, uint32_t>(LoadU32{extra}, nlong, extra, (uint32_t *)hscan_tmp, s);
-        ntot = p0.ntiles + d2h(extra + nlong, s);
+        ntot = p0.ntiles + (p1.ntiles - nlong);   // (the scan's total: every long row's tiles but one -- no read-back)
         desc = sc.get<TileDesc>(ntot);
         tile_desc_kernel<(int)kCap><<<grid_for(p0.ntiles, 256), 256, 0, s>>>(p0.tile_rows, p0.ntiles, r1, io.row_off, base, 0u, j0, extra,
                                                                            nlong, tb, pl.vcol0, pl.vcol1, desc);
@@ -857,6 +879,7 @@ struct PanelSink {
 };
 
 // ---- stages shared by both entry points: partial products of each row -> final CSR ----------------
+constexpr uint64_t kPartialsOnDevice = ~0ull;   // merge_pipeline's P: not read back yet, it is d_row_off[M_all]
 template <class T>
 static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_t M_all, uint64_t N,
                            const uint64_t *d_row_off,
@@ -877,6 +900,26 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     // measured slower -- osp_merge_runs.h, tools/bench_merge -- and is not wired into the library.)
     const int colbits = std::max(1, bits_for(N));
 
+    // ---- final CSR arrays at an upper bound: nnz(C) <= sum_i min(U_i, N) -------------------------------
+    const uint64_t E = 4 + sizeof(T);
+    uint64_t cap_c;
+    uint64_t *ub = sc.get<uint64_t>(M + 1);  // exclusive scan of the per-row bounds (kept: streaming sizes panels with it)
+    {
+        Scratch us(ctx);
+        uint64_t *ub_tmp = us.get<uint64_t>(scan_scratch_entries(M + 1));
+        if (P != 0) device_exclusive_scan<RowUpperBound, uint64_t>(RowUpperBound{d_row_off + r_lo, N}, M, ub, ub_tmp, s);
+        if (P == 0) {
+            cap_c = 0;
+        } else if (P == kPartialsOnDevice) {   // the caller left the count of partial products on the device: one wait for both
+            Gather g(s);
+            g.add(&P, d_row_off + M_all);
+            g.add(&cap_c, (const uint64_t *)ub + M);
+            g.wait();
+            res->info.partials = P;
+        } else {
+            cap_c = d2h(ub + M, s);
+        }
+    }
     if (!sink) res->rowptr = (int64_t *)ctx->alloc((M + 1) * sizeof(int64_t));
     if (P == 0) {
         res->info.nnz_c = 0;
@@ -892,16 +935,6 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         }
         OSP_HIP(hipMemsetAsync(res->rowptr, 0, (M + 1) * sizeof(int64_t), s));
         return;
-    }
-    // ---- final CSR arrays at an upper bound: nnz(C) <= sum_i min(U_i, N) -------------------------------
-    const uint64_t E = 4 + sizeof(T);
-    uint64_t cap_c;
-    uint64_t *ub = sc.get<uint64_t>(M + 1);  // exclusive scan of the per-row bounds (kept: streaming sizes panels with it)
-    {
-        Scratch us(ctx);
-        uint64_t *ub_tmp = us.get<uint64_t>(scan_scratch_entries(M + 1));
-        device_exclusive_scan<RowUpperBound, uint64_t>(RowUpperBound{d_row_off + r_lo, N}, M, ub, ub_tmp, s);
-        cap_c = d2h(ub + M, s);
     }
     uint32_t *c_col = nullptr;
     T *c_val = nullptr;
@@ -991,7 +1024,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
             const uint64_t count = (npanels == 1) ? P : h_off[r1] - base;
             PanelPlan<T> plan(ctx);
             tm.begin(PH_MERGE);
-            plan_panel<T>(ctx, res, tm, plan, d_row_off, r0, r1, base, colbits, ds);
+            plan_panel<T>(ctx, res, tm, plan, d_row_off, r0, r1, base, count, colbits, ds);
             tm.end(PH_MERGE);
             tm.begin(PH_MUL);
             if (count) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm, plan.cells, plan.qstage);
@@ -1024,7 +1057,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         // ---- multiply (or scatter of CSR parts) ----
         PanelPlan<T> plan(ctx);
         tm.begin(PH_MERGE);
-        plan_panel<T>(ctx, res, tm, plan, d_row_off, r0, r1, base, colbits, ds);
+        plan_panel<T>(ctx, res, tm, plan, d_row_off, r0, r1, base, count, colbits, ds);
         tm.end(PH_MERGE);
         tm.begin(PH_MUL);
         if (count) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm, plan.cells, plan.qstage);
@@ -1291,7 +1324,9 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         sym_row_offsets_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(rows_sorted, offs_sorted, nnz, M, row_off, rowfirst);
         const uint64_t rw_cap = rowwise ? (uint64_t)TileCap<T>::value : 0ull;
         sym_scatter_offsets_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(perm, offs_sorted, rows_sorted, row_off, rw_cap, nnz, chunk_off);
-        P = d2h(offs_sorted + nnz, s);
+        // (the product proper reads P together with the size of the result, merge_pipeline: one stream round trip less)
+        if (partials_only || rowwise || row_sharded) P = d2h(offs_sorted + nnz, s);
+        else P = kPartialsOnDevice;
         if (direct) dsrc = DirectSrc{rowfirst, offs_sorted, bs_sorted, perm, b_colidx, chunk_off, direct_max};
         if (rowwise) {
             ct = ChunkTable<T>{offs_sorted, bs_sorted, perm, rowfirst, a_vals + e0, b_colidx, b_vals, (uint32_t)rw_cap, 1u};

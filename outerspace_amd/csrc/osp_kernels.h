@@ -132,6 +132,21 @@ __device__ __forceinline__ uint64_t upper_bound_dev(const T *a, uint64_t lo, uin
     }
     return lo;
 }
+// upper_bound_dev by a whole wave: 64 probes per step (a 2^22 range takes 4 round trips instead of 22); every lane of the
+// wave must call it with the same arguments, every lane gets the result
+template <class T, class X>
+__device__ __forceinline__ uint64_t wave_upper_bound(const T *a, uint64_t lo, uint64_t hi, X x) {
+    const uint64_t lane = lane_id();
+    while (hi - lo > 64) {
+        const uint64_t step = (hi - lo) / 64, p = lo + lane * step;   // probes lo, lo + step, ... (all below hi)
+        const int c = __popcll(__ballot((X)a[p] <= x));               // monotone: the first c probes hold values <= x
+        if (c == 0) return lo;
+        if (c < 64) hi = lo + (uint64_t)c * step;
+        lo = lo + (uint64_t)(c - 1) * step + 1;
+    }
+    const bool le = lane < hi - lo && (X)a[lo + lane] <= x;
+    return lo + (uint64_t)__popcll(__ballot(le));
+}
 // first index in [lo,hi) with a[idx] >= x
 template <class T, class X>
 __device__ __forceinline__ uint64_t lower_bound_dev(const T *a, uint64_t lo, uint64_t hi, X x) {
@@ -599,11 +614,17 @@ struct CoarseStartFlag {
     }
 };
 // counts[j] = tiles of coarse block j (tile_rows == nullptr), or write them at tile_base[j]
-__global__ void tile_walk_kernel(const uint32_t *cb_rows, uint32_t ncb, uint64_t r_end, const uint64_t *row_off,
+// (The number of coarse blocks stays on the device -- *ncb_p; the launch covers the host's upper bound ncb_max, and the
+// blocks beyond the real count get 0 tiles -- so that planning the tiles costs one read-back, not two.)
+__global__ void tile_walk_kernel(const uint32_t *cb_rows, const uint32_t *ncb_p, uint32_t ncb_max, uint64_t r_end, const uint64_t *row_off,
                                  uint64_t cap, uint32_t max_rows, const uint32_t *tile_base, uint32_t *counts,
                                  uint32_t *tile_rows) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ncb) return;
+    const uint32_t ncb = *ncb_p;
+    if (j >= ncb) {
+        if (!tile_rows && j < ncb_max) counts[j] = 0;
+        return;
+    }
     uint64_t r = cb_rows[j];
     const uint64_t end = (j + 1 < ncb) ? (uint64_t)cb_rows[j + 1] : r_end;
     uint32_t n = 0;

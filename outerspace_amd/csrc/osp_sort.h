@@ -229,12 +229,14 @@ struct SymEpilogue {
 __global__ void sym_chunk_len_kernel(const int64_t *a_colptr, const int64_t *b_rowptr, uint64_t k0, uint64_t k1, int64_t e0,
                                      uint64_t nnz, uint32_t *w, uint32_t *bs) {
     // the block's 256 consecutive entries lie in a short range of columns: two full searches per block (first and last
-    // entry), then every thread bisects that range only (~4 steps instead of ~22)
+    // entry, a wave each), then every thread bisects that range only (~4 steps instead of ~22)
     __shared__ uint64_t krange[2];
     const uint64_t tb = (uint64_t)blockIdx.x * blockDim.x;
-    if (threadIdx.x < 2) {
-        const uint64_t tt = threadIdx.x == 0 ? tb : min(tb + blockDim.x, nnz) - 1;
-        krange[threadIdx.x] = upper_bound_dev(a_colptr, k0, k1 + 1, e0 + (int64_t)tt) - 1;
+    if (threadIdx.x < 2 * kWave) {   // (one wave per end: 64 probes a step, 4 round trips where a bisection takes 22)
+        const unsigned wv = threadIdx.x / kWave;
+        const uint64_t tt = wv == 0 ? tb : min(tb + blockDim.x, nnz) - 1;
+        const uint64_t k = wave_upper_bound(a_colptr, k0, k1 + 1, e0 + (int64_t)tt) - 1;
+        if (threadIdx.x % kWave == 0) krange[wv] = k;
     }
     __syncthreads();
     const uint64_t t = tb + threadIdx.x;
