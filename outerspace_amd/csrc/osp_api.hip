@@ -414,6 +414,32 @@ static void copy_d2h(void *dst, const void *src, size_t bytes, hipStream_t s) {
     OSP_HIP(hipEventSynchronize(pb.done[i ^ 1]));
     memcpy((char *)dst + off_prev, pb.p + (i ^ 1) * chunk, n_prev);
 }
+// Zeroing up to four small arrays with ONE kernel.  hipMemsetAsync is a blit with barriers around it: in a kernel trace
+// each one costs 2-8 us plus ~10 us of idle stream before the next kernel starts, and a product issues half a dozen
+// (counters, flags, the tile status words); kernels queued behind kernels start without a gap.
+struct ZeroRegions {
+    uint32_t *p[4];
+    uint64_t words[4];
+};
+__global__ void zero_regions_kernel(const ZeroRegions z) {
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < z.words[r]; i += (uint64_t)gridDim.x * blockDim.x) z.p[r][i] = 0u;
+}
+static void zero_async(hipStream_t s, std::initializer_list<std::pair<void *, size_t>> regions) {   // (pointer, bytes: multiples of 4)
+    ZeroRegions z{};
+    int n = 0;
+    uint64_t most = 0;
+    for (auto &r : regions) {
+        if (n == 4 || (r.second & 3) || ((uintptr_t)r.first & 3)) throw Error(OSP_ERR_ARG, "zero_async: at most four word-aligned regions");
+        z.p[n] = (uint32_t *)r.first;
+        z.words[n] = r.second / 4;
+        most = std::max<uint64_t>(most, z.words[n]);
+        n++;
+    }
+    if (most == 0) return;
+    zero_regions_kernel<<<(unsigned)std::min<uint64_t>((most + 255) / 256, 2048), 256, 0, s>>>(z);
+}
 // several device scalars with ONE wait: a blocking read-back is a stream round trip, and a small product makes a dozen.
 // Three or more values are first gathered into consecutive device words by one tiny kernel and come back in ONE copy (a
 // copy of 8 bytes occupies the stream for 5-8 us: ten of them cost what the gather and its copy cost four times over).
@@ -606,7 +632,7 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
     for (int attempt = 0; attempt < 2; attempt++) {
         split_params_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(pl.p0.long_rows, nlong, row_off, colbits, row_max, bits_cap, ds ? ds->rowfirst : nullptr,
                                                                  ds ? ds->direct_max : 0ull, kCap, pl.hbits, pl.hmode, pl.nstretch, nseg, nhist, ncellh);
-        OSP_HIP(hipMemsetAsync(totals, 0, 6 * sizeof(uint64_t), s));
+        zero_async(s, {{totals, 6 * sizeof(uint64_t)}});
         mode_totals_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(pl.p0.long_rows, nlong, row_off, pl.hmode, totals);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{pl.nstretch}, nlong, pl.blkbase, pl.hscan_tmp, s);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nseg}, nlong, pl.vbase, pl.hscan_tmp, s);
@@ -784,7 +810,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
                 TileDesc *bdesc = sc.get<TileDesc>(nmid);
                 seg_tile_desc_kernel<<<grid_for(nmid, 256), 256, 0, s>>>(mid_list, nmid, vrow_off, pl.vcol0, pl.vcol1, bdesc);
                 uint32_t *bticket = sc.get<uint32_t>(1);
-                OSP_HIP(hipMemsetAsync(bticket, 0, sizeof(uint32_t), s));
+                zero_async(s, {{bticket, sizeof(uint32_t)}});
                 const uint32_t bgrid = ctx->cus * (uint32_t)merge_wgs_per_cu<T, kBigTileThreads, kBigTileCap>();
                 OSP_WITH_RA(ctx, merge_tiles_kernel<T, kBigTileThreads, 32, kBigTileCap, kMergeMaxWgs, RA>
                             <<<std::min<uint32_t>(nmid, bgrid), kBigTileThreads, 0, s>>>(bdesc, nmid, lv, colbits, nullptr, bticket, nullptr, nullptr,
@@ -843,8 +869,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
     static const uint32_t want_shards = getenv("OSP_MERGE_SHARDS") ? std::min(std::max(atoi(getenv("OSP_MERGE_SHARDS")), 1), 16) : 1;
     const uint32_t nshards = ntot >= 1024 ? want_shards : 1u;
     uint32_t *ticket = sc.get<uint32_t>((uint64_t)(nshards + 1) * kTicketStride);
-    OSP_HIP(hipMemsetAsync(tile_status, 0, (uint64_t)ntot * sizeof(uint64_t), s));
-    OSP_HIP(hipMemsetAsync(ticket, 0, (uint64_t)(nshards + 1) * kTicketStride * sizeof(uint32_t), s));
+    zero_async(s, {{tile_status, (uint64_t)ntot * sizeof(uint64_t)}, {ticket, (uint64_t)(nshards + 1) * kTicketStride * sizeof(uint32_t)}});
     dbg_sync(s, "tile planning, splits, over-long segments");
     tm.begin(PH_MERGE_K);
     // persistent workgroups: as many as the LDS lets run at once
@@ -1000,9 +1025,8 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     }
     Part<T> *stage = sc.get<Part<T>>(max_panel);
     uint64_t *out_nnz = sc.get<uint64_t>((uint64_t)npanels + 1);  // nnz written before panel p
-    OSP_HIP(hipMemsetAsync(out_nnz, 0, sizeof(uint64_t), s));
     uint32_t *abort_word = sc.get<uint32_t>(1);   // raised by a tile whose predecessors never published (merge_tiles_kernel's watchdog)
-    OSP_HIP(hipMemsetAsync(abort_word, 0, sizeof(uint32_t), s));
+    zero_async(s, {{out_nnz, sizeof(uint64_t)}, {abort_word, sizeof(uint32_t)}});
     auto check_abort = [&](uint32_t flag) {
         if (flag) throw Error(OSP_ERR_HIP, "the merge made no progress for seconds (a tile's predecessors never published their sizes); "
                                            "with OSP_MERGE_SHARDS > 1 that happens when fewer workgroups than shards ever run side by side");
