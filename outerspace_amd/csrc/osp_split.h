@@ -637,7 +637,7 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
     __shared__ uint16_t nxt[NFINE];          // first bin of the range that follows a range starting at this bin
     __shared__ uint8_t lut[NFINE];
     __shared__ uint32_t rbin0[kDirectMaxRanges + 2], roff[kDirectMaxRanges + 2], cursor[kDirectMaxRanges + 1];
-    __shared__ uint32_t cbs[CBL], cst[CBL + 1];
+    __shared__ uint32_t cbs[CBL], cst[CBL + 1];   // per chunk of the block: (B position - first entry number), first entry number
     __shared__ uint32_t cellm[kCellsLds], lsm[kCellsLds];
     __shared__ uint32_t psum[NT];
     __shared__ uint32_t scratch[NT / kWave + 1];
@@ -655,14 +655,14 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
     const uint32_t lutw = (nfine + 3) / 4;
     // descriptors of chunks [cb, cb + nb) -> cbs / cst (cst[nb] = entries of the block)
     auto load_block = [&](uint32_t cb, uint32_t nb) {
-        uint32_t len[CBL / NT], sum = 0;
+        uint32_t len[CBL / NT], bsv[CBL / NT], sum = 0;
 #pragma unroll
         for (int q = 0; q < CBL / NT; q++) {
             const uint32_t j = tid * (CBL / NT) + q;   // blocked: a thread owns consecutive chunks
-            len[q] = 0;
+            len[q] = 0; bsv[q] = 0;
             if (j < nb) {
                 const uint32_t c = c0 + cb + j;
-                cbs[j] = ct_bs[c];
+                bsv[q] = ct_bs[c];
                 len[q] = (uint32_t)(ct_off[c + 1] - ct_off[c]);
             }
             sum += len[q];
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
 #pragma unroll
         for (int q = 0; q < CBL / NT; q++) {
             const uint32_t j = tid * (CBL / NT) + q;
-            if (j < nb) cst[j] = ex;
+            if (j < nb) { cst[j] = ex; cbs[j] = bsv[q] - ex; }   // cbs: entry number in the block -> position in B (one read per entry)
             ex += len[q];
         }
         if (tid == 0) cst[nb] = total;
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
                 const bool valid = e < E;
                 while (valid && e >= cst[c + 1]) c++;
                 cu[u] = c;
-                col[u] = b_colidx[valid ? cbs[c] + (e - cst[c]) : 0u];   // clamped: the loads go out together
+                col[u] = b_colidx[valid ? cbs[c] + e : 0u];   // clamped: the loads go out together
             }
 #pragma unroll
             for (int u = 0; u < UNR; u++) f(cu[u], col[u], base + u * kWave + lane < E);
