@@ -42,6 +42,9 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_fetch(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
 }
+// the value of the lane below (lane 0: 0) on the DPP path: wave_shr:1.  (__shfl_up is a ds_bpermute: an LDS operation, and
+// the wait for it also waits for every LDS atomic still in flight.)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return dpp_fetch<0x138, 0xf>(v); }
 template <>
 __device__ __forceinline__ uint32_t wave_incl_scan<uint32_t>(uint32_t v) {
     v += dpp_fetch<0x111, 0xf>(v);  // row_shr:1

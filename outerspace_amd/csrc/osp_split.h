@@ -584,13 +584,16 @@ __global__ __launch_bounds__(kSplitRowThreads) void split_row_kernel(
 // Ranges of one row stay in column order, runs inside a range in chunk order (ascending k), entries inside a run in
 // column order: the layout a stable split of the k-ordered row would give.
 // head lanes of the runs of equal `key` among the valid lanes of a wave-load, and each run's length
-__device__ __forceinline__ bool wave_run_head(uint32_t key, bool valid, uint32_t &runlen) {
+// (the planner that calls this is bound by its VALU instructions: ballots straight into SGPRs, the lane's "lanes above me"
+// mask from the caller -- it does not change between calls)
+__device__ __forceinline__ uint64_t lanes_above_mask() { return lane_id() == 63 ? 0ull : (~0ull << (lane_id() + 1)); }
+__device__ __forceinline__ bool wave_run_head(uint32_t key, bool valid, uint32_t &runlen, uint64_t above) {
     const unsigned lane = lane_id();
-    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
+    const uint32_t prev = wave_shr1(key);
     const bool head = valid && (lane == 0 || key != prev);
-    const uint64_t heads = __ballot(head), vm = __ballot(valid);
-    const uint64_t rest = lane == 63 ? 0ull : (heads >> (lane + 1));
-    const uint32_t next = rest ? lane + 1 + (uint32_t)__builtin_ctzll(rest) : (uint32_t)__popcll(vm);  // valid lanes are a prefix
+    const uint64_t heads = __builtin_amdgcn_ballot_w64(head), vm = __builtin_amdgcn_ballot_w64(valid);
+    const uint64_t rest = heads & above;
+    const uint32_t next = rest ? (uint32_t)__builtin_ctzll(rest) : (uint32_t)__popcll(vm);  // valid lanes are a prefix
     runlen = next - lane;
     return head;
 }
@@ -600,6 +603,13 @@ __device__ __forceinline__ bool wave_run_head(uint32_t key, bool valid, uint32_t
 // dependent loads per chunk: 24 ms per launch on R-MAT-22 instead of 3).
 #ifndef OSP_DIRECT_UNR
 #define OSP_DIRECT_UNR 8
+#endif
+// The planner is bound by its VALU instructions (88 % VALU utilisation by the SQ counters, MEASUREMENTS.md 1.6), and merging
+// the runs of equal (chunk, range) keys of a wave-load before the LDS atomic (wave_run_head) is a dozen of them per load --
+// but it pays: with one atomic per entry instead (0) the kernel takes 18.3 ms per launch against 10.4, same-address LDS
+// atomics being resolved one after the other.
+#ifndef OSP_PLAN_RUNS
+#define OSP_PLAN_RUNS 1
 #endif
 #ifndef OSP_DIRECT_CHUNK_BLOCK
 #define OSP_DIRECT_CHUNK_BLOCK 512
@@ -646,6 +656,7 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
     if (h >= nlong || hmode[h] != kModeDirect) return;
     OSP_PLAN_DECL
     const unsigned tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const uint64_t above = lanes_above_mask();
     const uint32_t i = rows[h];
     const uint32_t c0 = rowfirst[i], nc = rowfirst[i + 1] - c0;
     const uint32_t b = hbits[h], nfine = 1u << b, Ta = nseg[h];
@@ -707,9 +718,13 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
         OSP_PLAN_MARK(1);   // chunk descriptors
         have_cb = cb; have_nb = nb; have_E = E;
         for_entries(nb, E, [&](uint32_t, uint32_t col, bool valid) {
+#if OSP_PLAN_RUNS
             const uint32_t bin = valid ? col >> sh : 0xffffffffu;
             uint32_t runlen;
-            if (wave_run_head(bin, valid, runlen)) atomicAdd(&hist[bin], runlen);
+            if (wave_run_head(bin, valid, runlen, above)) atomicAdd(&hist[bin], runlen);
+#else
+            if (valid) atomicAdd(&hist[col >> sh], 1u);
+#endif
         });
         __syncthreads();   // before the next block's descriptors replace these
         OSP_PLAN_MARK(2);   // histogram pass
@@ -774,9 +789,13 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
         have_cb = cb; have_nb = nb; have_E = E;
         OSP_PLAN_MARK(1);
         for_entries(nb, E, [&](uint32_t cl, uint32_t col, bool valid) {
-            const uint32_t key = valid ? cl * 256u + (uint32_t)lut[col >> sh] : 0xffffffffu;   // (chunk, range): T <= 255
+#if OSP_PLAN_RUNS
+            const uint32_t key = valid ? __umul24(cl, T) + (uint32_t)lut[col >> sh] : 0xffffffffu;   // the (chunk, range) cell; both factors < 2^24
             uint32_t runlen;
-            if (wave_run_head(key, valid, runlen)) atomicAdd(&cellm[(key >> 8) * T + (key & 255u)], runlen);
+            if (wave_run_head(key, valid, runlen, above)) atomicAdd(&cellm[key], runlen);
+#else
+            if (valid) atomicAdd(&cellm[__umul24(cl, T) + (uint32_t)lut[col >> sh]], 1u);   // (chunk, range): both below 2^24
+#endif
         });
         __syncthreads();
         OSP_PLAN_MARK(4);   // cell pass
