@@ -173,7 +173,7 @@ int main(int argc, char **argv) {
         {"radix NT256 cap1536 static nolb", 1536, run<256, 6, 1536>}, {"radix NT256 cap1536 static nosort+nolb", 1536, run<256, 7, 1536>},
         {"radix NT256 cap1536 b16 counters", 1536, run<256, 128, 1536>}, {"radix NT256 cap1536 b32 hash init", 1536, run<256, 256, 1536>},
         {"radix NT256 cap1536 old lds ops", 1536, run<256, 128 + 256, 1536>},
-        {"radix NT256 cap1536 4wg", 1536, run<256, 0, 1536, 4>}, {"radix NT256 cap1792 full", 1792, run<256, 0, 1792>},
+        {"radix NT256 cap1536 4wg", 1536, run<256, 0, 1536, 4>}, {"radix NT256 cap1264 6wg", 1264, run<256, 0, 1264, 6>}, {"radix NT256 cap1792 full", 1792, run<256, 0, 1792>},
         {"radix NT256 cap2048 full", 2048, run<256, 0, 2048>}, {"radix NT256 cap1280 6wg", 1280, run<256, 0, 1280, 6>},
         {"radix NT512 cap3072 full", 3072, run<512, 0, 3072>},
         {"radix NT384 cap2304 full", 2304, run<384, 0, 2304>}, {"radix NT320 cap1920 full", 1920, run<320, 0, 1920>},
