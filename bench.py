@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--rmat", default="mild",
                     help="R-MAT (a,b,c,d): mild=(.45,.22,.22,.11) [default: skewed, and C still fits one GPU's HBM] | "
                          "uniform=(.25,.25,.25,.25) | g500=(.57,.19,.19,.05) [scale-22 needs ~840 GB for C] | a,b,c,d")
-    ap.add_argument("--workload", default="rmat", choices=["rmat", "webgoogle"],
+    ap.add_argument("--workload", default="rmat", choices=["rmat", "webgoogle", "cage15"],
                     help="webgoogle = BASELINE configs[1]: the real SuiteSparse file when --a-mtx names it (or $OSP_WEBGOOGLE_MTX / "
                          "./web-Google.mtx exist), else its shape (916428 vertices, ~5.1 M pattern non-zeros, power-law degrees)")
     ap.add_argument("--a-mtx", default=None, help="MatrixMarket file of A: the product of real files instead of a synthetic matrix "
@@ -194,6 +194,41 @@ def webgoogle_device(seed, device, dtype):
     key = torch.unique(rows * n + cols)
     rows, cols = key // n, key % n
     vals = torch.ones(rows.numel(), device=device, dtype=dtype)
+    csr, csc = _compress(n, rows, cols, vals, device)
+    return n, csr, csc
+
+
+def cage15_device(seed, device, dtype, side=172):
+    """cage15-SHAPED matrix (SuiteSparse vanHeukelum/cage15: 5 154 859 rows, 99.2 M entries, 19.2 per row, a classic SpGEMM
+    benchmark whose square compresses about 2:1; the file is not available offline): a side^3 periodic lattice, every vertex
+    linked to itself, its 6 face and 12 edge neighbours (each kept with probability 0.85) and 3 random vertices.
+    side = 172: n = 5 088 448, ~97 M entries, ~1.9 G partial products in the square.  Every output row is short (~370 partial
+    products) and about half of the products are duplicates: the regime R-MAT does not cover."""
+    import torch
+    n = side ** 3
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    i = torch.arange(n, device=device, dtype=torch.int64)
+    x, y, z = i % side, (i // side) % side, i // (side * side)
+    rows, cols = [], []
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                if abs(dx) + abs(dy) + abs(dz) > 2:
+                    continue
+                t = ((x + dx) % side) + ((y + dy) % side) * side + ((z + dz) % side) * side * side
+                if dx == dy == dz == 0:
+                    rows.append(i); cols.append(t)
+                else:
+                    keep = torch.rand(n, generator=g, device=device) < 0.85
+                    rows.append(i[keep]); cols.append(t[keep])
+    for _ in range(3):
+        rows.append(i); cols.append(torch.randint(0, n, (n,), generator=g, device=device, dtype=torch.int64))
+    key = torch.unique(torch.cat(rows) * n + torch.cat(cols))
+    del rows, cols, x, y, z
+    rows, cols = key // n, key % n
+    del key
+    vals = torch.rand(rows.numel(), generator=g, device=device, dtype=dtype) + 0.5
     csr, csc = _compress(n, rows, cols, vals, device)
     return n, csr, csc
 
@@ -667,6 +702,9 @@ def main():
     elif args.workload == "webgoogle":
         n, csr, csc = webgoogle_device(args.seed, device, tdtype)
         workload_name = "web-Google-shaped synthetic pattern matrix (916428 vertices, power-law degrees), self-product"
+    elif args.workload == "cage15":
+        n, csr, csc = cage15_device(args.seed, device, tdtype)
+        workload_name = "cage15-shaped synthetic matrix (172^3 lattice vertices, 19-point stencil kept at 0.85 + 3 random links), self-product"
     else:
         n, csr, csc = rmat_device(args.scale, args.edge_factor, abcd, args.seed, device, tdtype)
         workload_name = (f"R-MAT scale-{args.scale} edge-factor-{args.edge_factor} (a,b,c,d)={abcd} seed {args.seed}, "
@@ -760,6 +798,7 @@ def main():
                     ("rmat22_g500_streamed", lambda: rmat_device(22, 16, gen.RMAT_PRESETS["g500"], args.seed, device, tdtype), True),
                     ("rmat20_g500_streamed", lambda: rmat_device(20, 16, gen.RMAT_PRESETS["g500"], args.seed, device, tdtype), True),
                     ("rmat22_uniform", lambda: rmat_device(22, 16, gen.RMAT_PRESETS["uniform"], args.seed, device, tdtype), False),
+                    ("cage15_shape", lambda: cage15_device(args.seed, device, tdtype), False),
                     ("webgoogle_shape", lambda: webgoogle_operands(args.seed, device, tdtype), False)):
                 note(f"extra workload {name}")
                 n2, csr2, csc2 = make()

@@ -624,6 +624,28 @@ def test_webgoogle_shape_full_size_vs_oracle(ctx, port):
     res.close()
 
 
+@pytest.mark.parametrize("tname", ["f64", "f32"])
+def test_lattice_shape_vs_oracle(ctx, port, tname):
+    """The cage15-shaped matrix of bench.py at a reduced size (40^3 = 64 000 vertices, ~1.2 M entries, ~24 M partial products,
+    about half of them duplicates -- R-MAT products hardly compress): the whole square against the plain-C oracle, bit for bit."""
+    import torch
+    from outerspace_amd.distributed import _as_tensor
+    dev = torch.device("cuda", 0)
+    tdt, ndt, vfmt = (torch.float64, np.float64, "<f8") if tname == "f64" else (torch.float32, np.float32, "<f4")
+    n, csr, csc = _bench_module().cage15_device(3, dev, tdt, side=40)
+    host = [t.cpu().numpy() for t in (*csc, *csr)]
+    host = [a.view(np.uint32) if a.dtype == np.int32 else a for a in host]
+    want = port.spgemm(n, n, n, *host)
+    assert n == 64000 and want["partials"] > 2 * len(want["colidx"]) * 0.8   # it does compress
+    res = ctx.spgemm_csc_csr_device(ndt, n, n, n, [t.data_ptr() for t in (*csc, *csr)], validate=True)
+    assert res.info["partials"] == want["partials"] and res.nnz == len(want["colidx"])
+    rp, ci, va = res.device_ptrs()
+    assert torch.equal(_as_tensor(rp, n + 1, "<i8", dev, torch.int64), torch.from_numpy(want["rowptr"]).to(dev))
+    assert torch.equal(_as_tensor(ci, res.nnz, "<i4", dev, torch.int32), torch.from_numpy(want["colidx"].view(np.int32)).to(dev))
+    assert torch.equal(_as_tensor(va, res.nnz, vfmt, dev, tdt), torch.from_numpy(want["vals"]).to(dev))
+    res.close()
+
+
 def test_rmat22_full_size_properties_and_slab_parity(ctx, port):
     """configs[2] at its full size (R-MAT scale 22, edge factor 16, (a,b,c,d) = (.45,.22,.22,.11), seed 1: nnz 67 M,
     P = 1.19e10, nnz(C) = 1.15e10 -- 138 GB of CSR, far beyond what the oracle can form):
