@@ -1463,11 +1463,10 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
             }
         }
         OSP_PROF_MARK(7);
-        uint32_t oslot[IPT];
+        const uint32_t oslot0 = ex;   // output slot of the first run that starts among the thread's entries
 #pragma unroll
         for (int q = 0; q < IPT; q++) {
             const uint32_t i = ib + q;
-            oslot[q] = ex;
             if (i < n) {
                 sm.rank[i] = (uint16_t)ex;  // output slot of the run that starts at/behind i (the counters are dead)
                 ex += (hmask >> q) & 1u;
@@ -1478,27 +1477,60 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
         // A head walks at most kRunShort entries itself.  A longer run (a hub column: at Graph500 skew one output entry of a
         // tile is fed by hundreds of products) would keep ONE lane busy for three dependent LDS round trips per entry while
         // the rest of the workgroup waits; it is handed, with the sum so far, to a whole wave below.
+        // A thread's IPT sorted entries are in its registers first (independent gathers, all in flight together); the runs
+        // that lie inside them are summed there, left to right, with the head flags telling where a run ends -- no key
+        // compares, no loop of dependent LDS reads per run.  Only the LAST run of the block can reach into the entries of the
+        // next threads: its sum goes on from LDS, up to kRunShort entries from its head; what is longer than that goes to a
+        // whole wave below.  (Runs were walked entry by entry from LDS before: tiles of products that compress 2:1 spent a
+        // quarter of their time there, tools/bench_merge DUPWIN=230.)  Results sit at the run's last entry of the block.
+        static_assert(IPT <= kRunShort, "the part of a run inside one thread's entries is never longer than a head's own share");
         T acc[IPT];
-        uint32_t ocol[IPT], lmask = 0;
+        uint32_t ocol[IPT], lmask = 0, tmask = 0;
+        {
+            T v[IPT];
 #pragma unroll
-        for (int q = 0; q < IPT; q++) {
-            const uint32_t i = ib + q;
-            acc[q] = 0; ocol[q] = 0;
-            if (i < n && ((hmask >> q) & 1u)) {
-                const uint32_t k = skey[i];
-                T a = sval[spos[i]];
-                const uint32_t ulim = min(n, i + (uint32_t)kRunShort);
-                uint32_t u = i + 1;
+            for (int q = 0; q < IPT; q++) {
+                const uint32_t i = ib + q;
+                v[q] = i < n ? sval[spos[i]] : T(0);
+            }
+            T cur = T(0);
+#pragma unroll
+            for (int q = 0; q < IPT; q++) {
+                const uint32_t i = ib + q;
+                const bool hd = (hmask >> q) & 1u;
+                cur = hd ? v[q] : cur + v[q];   // (the sum STARTS as the head's value: keeps a lone -0.0)
+                const bool nexthd = q + 1 < IPT ? ((hmask >> (q + 1)) & 1u) != 0 : true;
+                const bool tail = i < n && (i + 1 >= n || nexthd) && (hmask & ((2u << q) - 1u)) != 0;   // of a run that started in this block
+                acc[q] = cur;
+                ocol[q] = 0;
+                tmask |= (tail ? 1u : 0u) << q;
+            }
+        }
+        if (tmask) {
+            const int qt = 31 - __builtin_clz(tmask);                 // the block's last run ends (so far) here
+            const uint32_t it = ib + (uint32_t)qt;
+            if (qt == IPT - 1 && it + 1 < n) {                        // it may go on behind the block
+                const uint32_t ih = ib + (uint32_t)(31 - __builtin_clz(hmask));   // its head
+                const uint32_t k = skey[it];
+                T a = acc[IPT - 1];
+                const uint32_t ulim = min(n, ih + (uint32_t)kRunShort);
+                uint32_t u = it + 1;
                 for (; u < ulim && skey[u] == k; u++) a += sval[spos[u]];
                 if (u == ulim && u < n && skey[u] == k) {
                     const uint32_t idx = atomicAdd(&sm.nlongrun, 1u);
                     sm.long_sum()[idx] = a;
                     sm.long_pos()[idx] = (uint16_t)u;
-                    lmask |= 1u << q;
+                    lmask |= 1u << (IPT - 1);
                     a = index_as_value<T>(idx);
                 }
-                acc[q] = a;
-                ocol[q] = relkey ? k + cbase : (k & colmask);
+                acc[IPT - 1] = a;
+            }
+#pragma unroll
+            for (int q = 0; q < IPT; q++) {
+                if ((tmask >> q) & 1u) {
+                    const uint32_t k = skey[ib + q];
+                    ocol[q] = relkey ? k + cbase : (k & colmask);
+                }
             }
         }
         if (tid == 0) s_tnext = tn_reg;
@@ -1529,10 +1561,10 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
         // lanes on consecutive addresses
 #pragma unroll
         for (int q = 0; q < IPT; q++) {
-            const uint32_t i = ib + q;
-            if (i < n && ((hmask >> q) & 1u)) {
-                skey[oslot[q]] = ocol[q];
-                sval[oslot[q]] = ((lmask >> q) & 1u) ? sm.long_sum()[value_as_index<T>(acc[q])] : acc[q];
+            if ((tmask >> q) & 1u) {   // the run that ends at the thread's entry q: its slot is its head's
+                const uint32_t slot = oslot0 + (uint32_t)__popc(hmask & ((2u << q) - 1u)) - 1u;
+                skey[slot] = ocol[q];
+                sval[slot] = ((lmask >> q) & 1u) ? sm.long_sum()[value_as_index<T>(acc[q])] : acc[q];
             }
         }
         if (tid == 0 && tn_reg < ntiles) s_dnext = desc[tn_reg];

@@ -34,6 +34,14 @@ __global__ void fill_sorted_kernel(uint32_t *pcol, uint64_t n, uint32_t clen) {
     const uint32_t stride = (1u << 22) / clen;
     pcol[i] = (uint32_t)(x % stride) + (uint32_t)j * stride;
 }
+// duplicates (DUPWIN=w): every row draws its columns from a window of w columns of its own -- rowlen draws from w values
+__global__ void fill_dup_kernel(uint32_t *pcol, uint64_t n, uint32_t rowlen, uint32_t win) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t x = i * 0x9E3779B97F4A7C15ull; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    uint64_t r = (i / rowlen) * 0xD6E8FEB86659FD93ull; r ^= r >> 32;
+    pcol[i] = (uint32_t)((r + x % win) & ((1u << 22) - 1));
+}
 // level-1 look-alike (L1BITS=b): the rows of a tile are consecutive column ranges of width 2^b / rpt, key = col - 0
 __global__ void fill_l1_kernel(uint32_t *pcol, uint64_t n, uint32_t rowlen, uint32_t rpt, uint32_t width) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -143,6 +151,7 @@ int main(int argc, char **argv) {
     const uint32_t clen = argc > 4 ? atoi(argv[4]) : 16;
     fill_kernel<<<(unsigned)((P + 255) / 256), 256>>>(pcol, pval, P);
     fill_sorted_kernel<<<(unsigned)((P + 255) / 256), 256>>>(pcol, P, clen);
+    if (getenv("DUPWIN")) fill_dup_kernel<<<(unsigned)((P + 255) / 256), 256>>>(pcol, P, rowlen, (uint32_t)atoi(getenv("DUPWIN")));
     const uint32_t l1bits = getenv("L1BITS") ? atoi(getenv("L1BITS")) : 0;
     if (l1bits) fill_l1_kernel<<<(unsigned)((P + 255) / 256), 256>>>(pcol, P, rowlen, rpt, (1u << l1bits) / rpt);
     CK(hipMalloc(&g_arow, (M + 1) * 4)); CK(hipMalloc(&g_chunk_start, (P / clen + 2) * 8));
