@@ -664,8 +664,11 @@ __global__ void compact_flagged_kernel(F f, const uint32_t *scan, uint64_t n, ui
 // rows are written ONCE, straight to c_col / c_val / c_rowptr (no per-row compaction pass).
 constexpr uint64_t kStatusAgg = 1ull << 62, kStatusPrefix = 2ull << 62, kStatusMask = (1ull << 62) - 1;
 
+// (8 until late in round 3.  With the runs' first entries summed from registers, 16 costs the skewed products nothing and a
+// product whose output rows are dense -- 32768^2, 634 entries per row, every output entry fed by ~12 products -- a third less
+// merge time: 57.2 -> 40.2 ms per launch; 32 measures the same as 16.)
 #ifndef OSP_RUN_SHORT
-#define OSP_RUN_SHORT 8
+#define OSP_RUN_SHORT 16
 #endif
 constexpr int kRunShort = OSP_RUN_SHORT;  // entries of a run its head thread sums itself; the rest of a longer run: a wave (merge_tiles_kernel)
 template <class T> __device__ __forceinline__ T index_as_value(uint32_t i);
