@@ -625,9 +625,11 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
     // debugging aid: OSP_SPLIT_ROW_MAX moves the boundary between the two split kernels (tests run both on small inputs)
     const uint64_t row_max = getenv("OSP_SPLIT_ROW_MAX") ? strtoull(getenv("OSP_SPLIT_ROW_MAX"), nullptr, 10) : kSplitRowMax;
     // no more ranges than make a range as narrow as the dense accumulators take (osp_split.h, kDenseBits): beyond that
-    // a finer split only shortens the runs the scatter writes -- whatever a range of <= 1024 columns holds is summed
-    // without a sort.  (Only bites when N < 2^22: 4096 ranges of 1024 columns.)
-    const int bits_cap = getenv("OSP_SPLIT_BITS_CAP") ? atoi(getenv("OSP_SPLIT_BITS_CAP")) : std::max(colbits - kDenseBits, kSplitRowBits);
+    // a finer split only shortens the runs the scatter writes -- whatever a range of <= 2048 columns holds is summed
+    // without a sort.  It bites for rows with more than ~0.4 products per column of B.  (Until late in round 3 the cap
+    // was never below kSplitRowBits, i.e. without effect for N < 2^20: a product with dense output rows -- 32768^2, 634
+    // entries per row -- sorted 512 ranges of 64 columns per row, 370 ms; with 16 ranges of 2048 columns it takes 197.)
+    const int bits_cap = getenv("OSP_SPLIT_BITS_CAP") ? atoi(getenv("OSP_SPLIT_BITS_CAP")) : std::max(colbits - kDenseBits, 1);
     uint64_t ndcell = 0, tot[6] = {0, 0, 0, 0, 0, 0};
     for (int attempt = 0; attempt < 2; attempt++) {
         split_params_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(pl.p0.long_rows, nlong, row_off, colbits, row_max, bits_cap, ds ? ds->rowfirst : nullptr,
