@@ -69,6 +69,7 @@ constexpr uint8_t kModeSplitRow = 0, kModeStretch = 1, kModeDirect = 2;
 #endif
 constexpr int kDirectThreads = OSP_DIRECT_THREADS;
 constexpr int kDirectCells = 4096;     // LDS words of direct_plan_kernel's (chunk, range) cells: counts and in-chunk starts
+constexpr uint64_t kDirectDenseMax = 1ull << 20;   // longest dense row (ranges capped at the accumulators' width) written directly
 constexpr int kDirectMaxRanges = 255;  // ranges per direct row (a byte per fine bin names the range)
 constexpr uint64_t kDirectRowCells = 1ull << 19;  // (chunk, range) cells of ONE direct row at most
 // per long row h: b = number of split bits, the mode, and the sizes that get scanned.
@@ -87,12 +88,18 @@ __global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const
     while (b < kSplitMaxBits && (1ull << b) < want) b++;
     b = min(b, min(colbits, bits_cap));
     const bool big = U > row_max || b > kSplitRowBits;
-    const uint32_t ns = big ? (uint32_t)((U + kSplitJob - 1) / kSplitJob) : 0u;  // 0 stretches = one-workgroup row
-    const uint64_t nranges = 2 * U / cap + 2;
+    // A row whose bins were capped (a "dense" row: more than ~0.4 products per column) has at most 2^b ranges, each as wide as
+    // a dense accumulator, whatever its length: the multiply can write it by range directly although it is longer than what
+    // one workgroup splits -- up to kDirectDenseMax products, which one workgroup of the planner walks in a few milliseconds.
+    const bool capped = (1ull << b) < want;
+    const uint64_t nranges = min(2 * U / cap + 2, (1ull << b) + 1);
     const uint64_t nc = rowfirst != nullptr ? (uint64_t)(rowfirst[rows[h] + 1] - rowfirst[rows[h]]) : 0ull;
+    const uint64_t dmax = (capped && direct_max) ? max(direct_max, kDirectDenseMax) : direct_max;
     // (a row of very many tiny chunks -- nc * nranges cells -- would keep ONE workgroup of the planner busy for milliseconds,
     // block of chunks after block of chunks: such a row is cheaper to split)
-    const bool direct = rowfirst != nullptr && !big && U <= direct_max && nranges <= (uint64_t)kDirectMaxRanges && nc * nranges <= kDirectRowCells;
+    const bool direct = rowfirst != nullptr && b <= kSplitRowBits && (!big || capped) && U <= dmax && nranges <= (uint64_t)kDirectMaxRanges &&
+                        nc * nranges <= kDirectRowCells;
+    const uint32_t ns = (big && !direct) ? (uint32_t)((U + kSplitJob - 1) / kSplitJob) : 0u;  // 0 stretches = one-workgroup row
     hbits[h] = (uint8_t)b;
     hmode[h] = direct ? kModeDirect : big ? kModeStretch : kModeSplitRow;
     nstretch[h] = ns;

@@ -1017,6 +1017,26 @@ def test_direct_rows_written_by_the_multiply(port, monkeypatch, _ctx_shared, dir
             got.close()
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_dense_long_rows_are_direct_rows(port, monkeypatch, _ctx_shared, dt):
+    """Rows with more products than one workgroup splits (here: more than OSP_SPLIT_ROW_MAX = 4096) whose column ranges were
+    capped at the width of a dense accumulator -- few columns, many products per column -- are written by range by the
+    multiply phase as well and summed by the dense accumulators (osp_split.h, split_params_kernel: `capped`): no stretch split.
+    n = 2048 columns (two ranges of 1024 columns), ~100 entries per row, ~10 000 products per output row."""
+    monkeypatch.setenv("OSP_SPLIT_ROW_MAX", "4096")
+    ctx = _ctx_shared
+    n, rows, cols, vals = gen.rmat_coo(11, 100, "uniform", seed=9, dtype=dt)
+    for cap in (0, 1 << 22):
+        got, want = run_both(ctx, port, n, n, n, (rows, cols, vals), (rows, cols, vals), dt, partial_capacity=cap)
+        i = got.info
+        assert i["heavy_rows"] == n and i["direct_rows"] == n and i["direct_partials"] == i["heavy_partials"] > 4096 * n
+        assert i["split_launches"] == 0
+        if cap:
+            assert i["panels"] > 1
+        assert_same(got, want)
+        got.close()
+
+
 def test_record_parts_are_validated(_ctx_shared):
     """osp_merge_record_parts with cfg.validate: a column beyond N or a broken offset array is an error code, not an
     out-of-bounds access on the device."""
