@@ -385,7 +385,10 @@ __global__ __launch_bounds__(kDenseWaves * kWave) void dense_segment_kernel(cons
     __builtin_amdgcn_wave_barrier();
     Part<T> *seg = qstage + s0;
     if constexpr (ATOMIC) {
-        constexpr int UNROLL = 4;  // four groups of loads in flight; the atomics are issued group by group, in order
+#ifndef OSP_DENSE_UNROLL
+#define OSP_DENSE_UNROLL 16   // (4 until late in round 3; two workgroups of four waves per CU live on what each wave keeps in flight: Graph500 scale 18 ef 64 499 / 475 / 467 ms with 4 / 8 / 16)
+#endif
+        constexpr int UNROLL = OSP_DENSE_UNROLL;  // groups of loads in flight; the atomics are issued group by group, in order
         for (uint64_t i0 = 0; i0 < m; i0 += (uint64_t)UNROLL * kWave) {
             PartWords<T> rec[UNROLL];
 #pragma unroll
