@@ -1037,6 +1037,33 @@ def test_dense_long_rows_are_direct_rows(port, monkeypatch, _ctx_shared, dt):
         got.close()
 
 
+@pytest.mark.parametrize("scale,ef,preset,row_max,direct_max,cap", [
+    (10, 64, "uniform", "2048", None, 0),          # every row long and dense: two ranges, all direct
+    (10, 64, "uniform", "2048", "0", 1 << 20),     # the same rows through the stretch split, several panels
+    (12, 100, "uniform", "8192", "16384", 0),      # capped rows beyond OSP_DIRECT_MAX: still direct (dense), by the cap
+    (12, 48, "g500", "4096", None, 1 << 21),       # skew: hub rows far beyond 2^20 / row_max products next to short ones
+    (13, 32, "mild", "1024", "3000", 0),           # narrow limits: direct, split and stretch rows in one product
+    (9, 200, "uniform", "60000", None, 0),         # 512 columns: a single range per row
+])
+def test_dense_and_small_column_counts(port, monkeypatch, _ctx_shared, scale, ef, preset, row_max, direct_max, cap):
+    """Matrices with few columns (2^9 .. 2^13) whose long rows hold many products per column: the column ranges of such
+    rows are capped at the dense accumulators' width (osp_api.hip, bits_cap) and the rows are written by range directly
+    whatever their length (osp_split.h, `capped`).  Limits moved so that every combination of direct / split / stretch rows and
+    of dense / sorted segments occurs at sizes the oracle forms in seconds; same bits as the oracle."""
+    monkeypatch.setenv("OSP_SPLIT_ROW_MAX", row_max)
+    if direct_max is not None:
+        monkeypatch.setenv("OSP_DIRECT_MAX", direct_max)
+    ctx = _ctx_shared
+    for dt in (np.float64, np.float32):
+        n, rows, cols, vals = gen.rmat_coo(scale, ef, preset, seed=scale + ef, dtype=dt)
+        got, want = run_both(ctx, port, n, n, n, (rows, cols, vals), (rows, cols, vals), dt, partial_capacity=cap)
+        assert got.info["heavy_rows"] > 0
+        if cap:
+            assert got.info["panels"] > 1
+        assert_same(got, want)
+        got.close()
+
+
 def test_record_parts_are_validated(_ctx_shared):
     """osp_merge_record_parts with cfg.validate: a column beyond N or a broken offset array is an error code, not an
     out-of-bounds access on the device."""
