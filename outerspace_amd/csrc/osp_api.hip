@@ -1192,6 +1192,17 @@ static void check_flags(uint32_t f, const char *what) {
     if (f & kFlagUnsorted) throw Error(OSP_ERR_UNSORTED, std::string(what) + ": indices inside a segment are not ascending");
 }
 
+// *out += sum_k nnz(A[:,k]) * nnz(B[k,:]) over all k (one atomic per workgroup)
+__global__ void count_partials_kernel(const int64_t *a_colptr, const int64_t *b_rowptr, uint64_t K, unsigned long long *out) {
+    __shared__ uint64_t scratch[256 / kWave + 1];
+    uint64_t sum = 0;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < K; k += (uint64_t)gridDim.x * blockDim.x)
+        sum += (uint64_t)(a_colptr[k + 1] - a_colptr[k]) * (uint64_t)(b_rowptr[k + 1] - b_rowptr[k]);
+    uint64_t total;
+    block_excl_scan<uint64_t, 256>(sum, scratch, &total);
+    if (threadIdx.x == 0 && total) atomicAdd(out, (unsigned long long)total);
+}
+
 template <class T>
 static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint64_t N, const int64_t *a_colptr_in,
                         const uint32_t *a_rowidx_in, const T *a_vals_in, const int64_t *b_rowptr_in,
@@ -1207,8 +1218,19 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     const int64_t *a_colptr = to_device(sc, a_colptr_in, K + 1, space, s);
     const int64_t *b_rowptr = to_device(sc, b_rowptr_in, K + 1, space, s);
     int64_t nnz_a, nnz_b;
-    if (space == OSP_HOST) { nnz_a = a_colptr_in[K]; nnz_b = b_rowptr_in[K]; }
-    else { Gather g(s); g.add(&nnz_a, a_colptr + K); g.add(&nnz_b, b_rowptr + K); g.wait(); }
+    // (with them comes the number of partial products of the whole product -- a sum over k of two differences: what decides
+    // whether a product of few non-zeros still plans direct rows, see `direct` below)
+    uint64_t p_all = 0;
+    unsigned long long *p_all_dev = (unsigned long long *)sc.get<uint64_t>(1);
+    zero_async(s, {{p_all_dev, sizeof(uint64_t)}});
+    if (K) count_partials_kernel<<<(unsigned)std::min<uint64_t>(grid_for(K, 256), 4096), 256, 0, s>>>(a_colptr, b_rowptr, K, p_all_dev);
+    {
+        Gather g(s);
+        if (space == OSP_HOST) { nnz_a = a_colptr_in[K]; nnz_b = b_rowptr_in[K]; }
+        else { g.add(&nnz_a, a_colptr + K); g.add(&nnz_b, b_rowptr + K); }
+        g.add(&p_all, (const uint64_t *)p_all_dev);
+        g.wait();
+    }
     if (nnz_a < 0 || nnz_b < 0) throw Error(OSP_ERR_ARG, "negative nnz in pointer array");
     if ((uint64_t)nnz_a >= 0xffffffffull || (uint64_t)nnz_b >= 0xffffffffull)
         throw Error(OSP_ERR_ARG, "operands with >= 2^32 non-zeros are not supported");
@@ -1321,7 +1343,12 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     // milliseconds does not earn back (web-Google shape: 2.3 ms with the split, 2.7 with direct rows).  OSP_DIRECT_MIN_NNZ
     // moves that boundary (the tests set it to 0, so that their small inputs take the direct path).
     const uint64_t direct_min_nnz = getenv("OSP_DIRECT_MIN_NNZ") ? strtoull(getenv("OSP_DIRECT_MIN_NNZ"), nullptr, 10) : (8ull << 20);
-    const bool direct = nnz && nnz >= direct_min_nnz && (uint64_t)nnz_b < 0xffffffffull && nnz < 0xffffffffull && !partials_only &&
+    // ... unless its output rows are dense on average (more than 0.375 partial products per entry of the M x N result: the
+    // density from which a long row's column ranges are capped at the dense accumulators' width, plan_panel): such rows are
+    // written in a few wide ranges, long runs, and summed without a sort -- 4096^2 with 880 entries per row (3.6 M non-zeros,
+    // 3.2 G partial products) 44.4 -> 26.4 ms, Graph500 scale 14 ef 512 100 -> 79 ms.
+    const bool dense_avg = (long double)p_all * 8.0L >= 3.0L * (long double)M * (long double)N;
+    const bool direct = nnz && (nnz >= direct_min_nnz || dense_avg) && (uint64_t)nnz_b < 0xffffffffull && nnz < 0xffffffffull && !partials_only &&
                         !(getenv("OSP_DIRECT") && atoi(getenv("OSP_DIRECT")) == 0);
     const uint64_t direct_max = getenv("OSP_DIRECT_MAX") ? strtoull(getenv("OSP_DIRECT_MAX"), nullptr, 10) : kSplitRowMax;
     DirectSrc dsrc{};

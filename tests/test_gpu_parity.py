@@ -1064,6 +1064,23 @@ def test_dense_and_small_column_counts(port, monkeypatch, _ctx_shared, scale, ef
         got.close()
 
 
+def test_direct_rows_by_density_for_small_operands(port, monkeypatch, _ctx_shared):
+    """A product of few non-zeros keeps the split (OSP_DIRECT_MIN_NNZ, here: out of reach) -- unless its output rows are dense
+    on average (>= 0.375 partial products per entry of the M x N result): then its long rows are direct rows all the same."""
+    monkeypatch.setenv("OSP_DIRECT_MIN_NNZ", "1000000000")
+    ctx = _ctx_shared
+    n, rows, cols, vals = gen.rmat_coo(10, 64, "uniform", seed=3)      # ~3.7 M partial products for a 1024 x 1024 result
+    got, want = run_both(ctx, port, n, n, n, (rows, cols, vals), (rows, cols, vals), np.float64)
+    assert got.info["partials"] * 8 >= 3 * n * n and got.info["heavy_rows"] > 0 and got.info["direct_rows"] == got.info["heavy_rows"]
+    assert_same(got, want)
+    got.close()
+    n, rows, cols, vals = gen.rmat_coo(13, 16, "g500", seed=3)         # skewed, sparse result: long rows, but no density
+    got, want = run_both(ctx, port, n, n, n, (rows, cols, vals), (rows, cols, vals), np.float64)
+    assert got.info["partials"] * 8 < 3 * n * n and got.info["heavy_rows"] > 0 and got.info["direct_rows"] == 0
+    assert_same(got, want)
+    got.close()
+
+
 def test_record_parts_are_validated(_ctx_shared):
     """osp_merge_record_parts with cfg.validate: a column beyond N or a broken offset array is an error code, not an
     out-of-bounds access on the device."""

@@ -1,4 +1,4 @@
-for a in "--rmat g500 --scale 18 --edge-factor 64" "--workload cage15 --dtype f32" "--rmat uniform --scale 22 --edge-factor 3" "--rmat uniform --scale 20 --edge-factor 64" "--rmat mild --scale 16 --edge-factor 256"; do
+for a in "--rmat uniform --scale 12 --edge-factor 1000" "--rmat uniform --scale 18 --edge-factor 200" "--rmat g500 --scale 14 --edge-factor 512" "--rmat mild --scale 20 --edge-factor 32" "--rmat uniform --scale 24 --edge-factor 6"; do
   python3 bench.py $a --cpu-baseline 0 --extras 0 --ingest 0 --steps 2 --warmup 1 2>gpurun_out/pr.err > gpurun_out/pr.json || { echo "FAILED $a"; tail -3 gpurun_out/pr.err; continue; }
   python3 - "$a" <<PY
 import json,sys
