@@ -626,7 +626,7 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
     const uint64_t row_max = getenv("OSP_SPLIT_ROW_MAX") ? strtoull(getenv("OSP_SPLIT_ROW_MAX"), nullptr, 10) : kSplitRowMax;
     // no more ranges than make a range as narrow as the dense accumulators take (osp_split.h, kDenseBits): beyond that
     // a finer split only shortens the runs the scatter writes -- whatever a range of <= 2048 columns holds is summed
-    // without a sort.  It bites for rows with more than ~0.4 products per column of B.  (Until late in round 3 the cap
+    // without a sort.  It bites for rows with more than one product per 8 columns of B (kSplitTarget = 256 per 2048 columns).  (Until late in round 3 the cap
     // was never below kSplitRowBits, i.e. without effect for N < 2^20: a product with dense output rows -- 32768^2, 634
     // entries per row -- sorted 512 ranges of 64 columns per row, 370 ms; with 16 ranges of 2048 columns it takes 197.)
     const int bits_cap = getenv("OSP_SPLIT_BITS_CAP") ? atoi(getenv("OSP_SPLIT_BITS_CAP")) : std::max(colbits - kDenseBits, 1);
@@ -1343,7 +1343,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     // milliseconds does not earn back (web-Google shape: 2.3 ms with the split, 2.7 with direct rows).  OSP_DIRECT_MIN_NNZ
     // moves that boundary (the tests set it to 0, so that their small inputs take the direct path).
     const uint64_t direct_min_nnz = getenv("OSP_DIRECT_MIN_NNZ") ? strtoull(getenv("OSP_DIRECT_MIN_NNZ"), nullptr, 10) : (8ull << 20);
-    // ... unless its output rows are dense on average (more than 0.375 partial products per entry of the M x N result: the
+    // ... unless its output rows are dense on average (at least 0.375 partial products per entry of the M x N result -- three times the
     // density from which a long row's column ranges are capped at the dense accumulators' width, plan_panel): such rows are
     // written in a few wide ranges, long runs, and summed without a sort -- 4096^2 with 880 entries per row (3.6 M non-zeros,
     // 3.2 G partial products) 44.4 -> 26.4 ms, Graph500 scale 14 ef 512 100 -> 79 ms.

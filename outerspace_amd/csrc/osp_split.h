@@ -88,7 +88,7 @@ __global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const
     while (b < kSplitMaxBits && (1ull << b) < want) b++;
     b = min(b, min(colbits, bits_cap));
     const bool big = U > row_max || b > kSplitRowBits;
-    // A row whose bins were capped (a "dense" row: more than ~0.4 products per column) has at most 2^b ranges, each as wide as
+    // A row whose bins were capped (a "dense" row: more than one product per 8 columns: kSplitTarget products per range of 2^kDenseBits columns) has at most 2^b ranges, each as wide as
     // a dense accumulator, whatever its length: the multiply can write it by range directly although it is longer than what
     // one workgroup splits -- up to kDirectDenseMax products, which one workgroup of the planner walks in a few milliseconds.
     const bool capped = (1ull << b) < want;
