@@ -34,7 +34,10 @@ template <class T> struct TileCap;
 // (f32 values alias 4 bytes per entry, not 8: the same 31 KB of LDS hold a seventh more entries, and a tile costs a ticket
 // and a look-back whatever it holds)
 template <> struct TileCap<float> { static constexpr int value = OSP_TILE_CAP_F32; };
-template <> struct TileCap<double> { static constexpr int value = 1536; };
+#ifndef OSP_TILE_CAP_F64
+#define OSP_TILE_CAP_F64 1536
+#endif
+template <> struct TileCap<double> { static constexpr int value = OSP_TILE_CAP_F64; };
 constexpr int kMergeThreads = 256;
 constexpr int kTileMaxRows = kMergeThreads - 1;  // rows per tile: 8 row bits in the sort key, one row offset per thread
 constexpr int kMulThreads = 256;
