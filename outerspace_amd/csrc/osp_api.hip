@@ -889,9 +889,12 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
     tm.end(PH_MERGE_K);
     dbg_sync(s, "merge tiles");
     res->info.merge_launches++;
-    if (p1.nlong)
-        heavy_copy_kernel<T><<<p1.nlong * 8u, 256, 0, s>>>(p1.long_rows, p1.nlong, seg_src, seg_nnz, vptr, qstage, nullptr, nullptr,
+    if (p1.nlong) {
+        heavy_copy_kernel<T><<<grid_for(p1.nlong, 8), 256, 0, s>>>(p1.long_rows, p1.nlong, seg_src, seg_nnz, vptr, qstage, nullptr, nullptr,
+                                                                   io.c_col, io.c_val);
+        heavy_copy_rest_kernel<T><<<p1.nlong, 256, 0, s>>>(p1.long_rows, p1.nlong, seg_src, seg_nnz, vptr, qstage, nullptr, nullptr,
                                                            io.c_col, io.c_val);
+    }
     chain_finish_kernel<<<grid_for(std::max<uint32_t>(p0.nlong, 1), 256), 256, 0, s>>>(p0.long_rows, p0.nlong, vbase, vptr, io.out_out, r1,
                                                                                        io.c_rowptr);
     dbg_sync(s, "copy of reduced segments, chain finish");

@@ -1731,16 +1731,41 @@ __global__ void heavy_rows_kernel(const uint32_t *rows, const uint64_t *hoff, ui
     if (h >= nheavy) return;
     heavy_nnz[rows[h]] = (uint32_t)(headscan[hoff[h + 1]] - headscan[hoff[h]]);
 }
-// after merge_tiles_kernel fixed c_rowptr: move each long row's merged entries to their place
+// after merge_tiles_kernel fixed c_rowptr: move each reduced segment's merged entries to their place.
+// Two launches.  Most of these segments are dense accumulators' results or big in-place tiles (at most a few thousand
+// entries) and there are hundreds of thousands of them per panel at Graph500 skew: eight workgroups per segment (as it was until
+// late in round 3) were mostly workgroups with nothing to do -- 4.4 ms per panel went into dispatching them.  Now a WAVE copies
+// the first kHeavyCopyHead entries of a segment (two segments per wave, eight per workgroup), and a second launch, one
+// workgroup per segment, copies what lies beyond (the results of the global-sort path) and returns at once otherwise.
+constexpr uint32_t kHeavyCopyHead = 8192;
 template <class T>
-__global__ void heavy_copy_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *heavy_src,
-                                  const uint32_t *heavy_nnz, const int64_t *c_rowptr, const Part<T> *src_stage,
-                                  const uint32_t *scol, const T *sval, uint32_t *c_col, T *c_val) {
-    const uint32_t h = blockIdx.x >> 3, sub = blockIdx.x & 7u;  // a long row is copied by 8 workgroups
+__global__ __launch_bounds__(256) void heavy_copy_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *heavy_src,
+                                                         const uint32_t *heavy_nnz, const int64_t *c_rowptr, const Part<T> *src_stage,
+                                                         const uint32_t *scol, const T *sval, uint32_t *c_col, T *c_val) {
+    const unsigned lane = lane_id(), w = threadIdx.x >> 6;
+#pragma unroll
+    for (uint32_t j = 0; j < 2; j++) {
+        const uint32_t h = (blockIdx.x * 4u + w) * 2u + j;
+        if (h >= nheavy) return;
+        const uint32_t row = rows[h];
+        const uint64_t n = min((uint64_t)heavy_nnz[row], (uint64_t)kHeavyCopyHead), src = heavy_src[h], dst = (uint64_t)c_rowptr[row];
+        for (uint64_t i = lane; i < n; i += kWave) {
+            if (src_stage) { const Part<T> pp = src_stage[src + i]; c_col[dst + i] = pp.col; c_val[dst + i] = pp.val; }
+            else { c_col[dst + i] = scol[src + i]; c_val[dst + i] = sval[src + i]; }
+        }
+    }
+}
+template <class T>
+__global__ __launch_bounds__(256) void heavy_copy_rest_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *heavy_src,
+                                                              const uint32_t *heavy_nnz, const int64_t *c_rowptr, const Part<T> *src_stage,
+                                                              const uint32_t *scol, const T *sval, uint32_t *c_col, T *c_val) {
+    const uint32_t h = blockIdx.x;
     if (h >= nheavy) return;
     const uint32_t row = rows[h];
-    const uint64_t n = heavy_nnz[row], src = heavy_src[h], dst = (uint64_t)c_rowptr[row];
-    for (uint64_t i = (uint64_t)sub * blockDim.x + threadIdx.x; i < n; i += 8ull * blockDim.x) {
+    const uint64_t n = heavy_nnz[row];
+    if (n <= kHeavyCopyHead) return;
+    const uint64_t src = heavy_src[h], dst = (uint64_t)c_rowptr[row];
+    for (uint64_t i = kHeavyCopyHead + threadIdx.x; i < n; i += blockDim.x) {
         if (src_stage) { const Part<T> pp = src_stage[src + i]; c_col[dst + i] = pp.col; c_val[dst + i] = pp.val; }
         else { c_col[dst + i] = scol[src + i]; c_val[dst + i] = sval[src + i]; }
     }
