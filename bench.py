@@ -291,12 +291,23 @@ def ingest_report(ctx, n, csr, csc, np_dtype, device, args, ingest, with_referen
     ac = torch.repeat_interleave(torch.arange(n, device=device, dtype=torch.int32), (csc[0][1:] - csc[0][:-1]))
     br = torch.repeat_interleave(torch.arange(n, device=device, dtype=torch.int32), (csr[0][1:] - csr[0][:-1]))
     torch.cuda.synchronize()
-    res = ctx.spgemm_coo_device(np_dtype, n, n, n, nnz_a, (ar.data_ptr(), ac.data_ptr(), csc[2].data_ptr()),
-                                nnz_b, (br.data_ptr(), csr[1].data_ptr(), csr[2].data_ptr()))
-    ms = float(res.info["ms_ingest"])
-    res.close()
+    # one cold call, then the median of five warm ones.  The cold call pays for the sort buffers (hipMalloc of a few GB
+    # of pool memory the products before it never asked for, and the driver clearing the pages): round 3's driver line
+    # reported ONE cold call (31.7 ms) where every profile of the builder, taken warm, showed 8.7-9.0 ms.
+    ms_all = []
+    for _ in range(6):
+        # (the conversions are what is timed; the product behind them is cut down to one column of k)
+        res = ctx.spgemm_coo_device(np_dtype, n, n, n, nnz_a, (ar.data_ptr(), ac.data_ptr(), csc[2].data_ptr()),
+                                    nnz_b, (br.data_ptr(), csr[1].data_ptr(), csr[2].data_ptr()), k_range=(0, 1))
+        ms_all.append(float(res.info["ms_ingest"]))
+        res.close()
+    ms_cold, ms_warm = ms_all[0], sorted(ms_all[1:])
+    ms = ms_warm[len(ms_warm) // 2]
     model = 100.0 * (nnz_a + nnz_b)   # ~100 B per non-zero (keys, payloads and histograms of the passes)
-    ingest["device_coo_to_compressed"] = {"ms": ms, "nnz_a": nnz_a, "nnz_b": nnz_b, "model_bytes": model,
+    ingest["device_coo_to_compressed"] = {"ms": ms, "ms_cold_first_call": ms_cold, "ms_warm_calls": ms_warm,
+                                          "timing": "median of 5 warm calls (HIP events around the conversions); the first call also pays for the "
+                                                    "pool's sort buffers",
+                                          "nnz_a": nnz_a, "nnz_b": nnz_b, "model_bytes": model,
                                           "GBps": model / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                                           "frac_of_peak": model / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0,
                                           "M_nnz_per_s": (nnz_a + nnz_b) / (ms * 1e-3) / 1e6 if ms > 0 else 0.0}
@@ -376,7 +387,7 @@ def expected_value_sum(n, csr, csc, device):
 
 
 # ---- the CPU reference on a k-slab, and the GPU checked against it ---------------------------------------------------------
-def cpu_baseline(ctx, csc, csr, n, target_partials, np_dtype, ptrs):
+def cpu_baseline(ctx, csc, csr, n, target_partials, np_dtype, ptrs, full=False):
     """Time the reference algorithm (cscMulcsr + deduplicateCOO, SimSpGEMM.cpp:265-281,:519-535) on one host core over a
     contiguous k-slab holding about `target_partials` partial products, then run the GPU on the SAME slab (k_range) and
     compare: coordinates must be identical, values within 1e-6 (f64) / 1e-5 (f32) relative -- bit-identical when the
@@ -389,7 +400,7 @@ def cpu_baseline(ctx, csc, csr, n, target_partials, np_dtype, ptrs):
     cum = torch.cumsum(w, 0)
     total = int(cum[-1])
     k1 = int(torch.searchsorted(cum, torch.tensor([int(min(target_partials, total))], device=cum.device))[0]) + 1
-    k1 = max(1, min(k1, n))
+    k1 = n if full else max(1, min(k1, n))   # full: the whole product ("run it in full for C2 and C3-uniform")
     a1, b1 = int(colptr[k1]), int(rowptr[k1])
     ac = colptr[:k1 + 1].cpu().numpy()
     bc = rowptr[:k1 + 1].cpu().numpy()
@@ -410,7 +421,7 @@ def cpu_baseline(ctx, csc, csr, n, target_partials, np_dtype, ptrs):
         nnzc, P, secs = len(r["colidx"]), r["partials"], sum(r["secs"])
         want_rowptr, want_cols, want_vals = r["rowptr"], r["colidx"], r["vals"]
     out = {"value": nnzc / secs, "unit": "nnz/s", "cores": 1, "kind": kind,
-           "sample": f"k-slab [0,{k1}) of the same matrix: {P} partial products -> {nnzc} nnz in {secs:.2f} s "
+           "sample": ("the WHOLE product" if full else f"k-slab [0,{k1}) of the same matrix") + f": {P} partial products -> {nnzc} nnz in {secs:.2f} s "
                      f"({P / secs / 1e6:.2f} M partials/s); host has {os.cpu_count()} cores, the reference is single-threaded",
            "partials_per_s": P / secs, "seconds": secs}
     # ---- the GPU on the same slab ----
@@ -433,7 +444,9 @@ def cpu_baseline(ctx, csc, csr, n, target_partials, np_dtype, ptrs):
         par["bit_identical_values"] = bool(np.array_equal(got, want_vals))
         if par["max_rel_err"] > tol or (kind == "port" and not par["bit_identical_values"]):
             problems.append(f"values differ by {par['max_rel_err']:.3e} relative")
+        del err, got
     res.close()
+    del want_rowptr, want_cols, want_vals, r
     if problems:
         par["status"] = "MISMATCH: " + "; ".join(problems)
     return out, par
@@ -469,6 +482,35 @@ def make_step(ctx, n, csr, csc, np_dtype, tdtype, device, partial_capacity, stre
             res.close()
             return info
     return step, ptrs
+
+
+def library_id():
+    """What identifies the kernels a number was measured on: a hash of the library's sources (and of the built .so)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    src = sorted(glob.glob(os.path.join(ROOT, "outerspace_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "outerspace_amd", "csrc", "*.hip")) +
+                 glob.glob(os.path.join(ROOT, "outerspace_amd", "csrc", "*.cpp")))
+    for path in src:
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    out = {"kernel_source_sha16": h.hexdigest()[:16]}
+    so = os.path.join(ROOT, "outerspace_amd", "libouterspace_spgemm.so")
+    if os.path.exists(so):
+        with open(so, "rb") as f:
+            out["so_sha16"] = hashlib.sha256(f.read()).hexdigest()[:16]
+    return out
+
+
+def add_measured_peak(roof, copy_gbps):
+    """Both fractions: of the data sheet's 8 TB/s and of what a plain copy reached on this box in this run."""
+    roof["peak_measured"] = copy_gbps
+    roof["peak_measured_what"] = ("16-bytes-per-lane copy of 2 GiB (read + written bytes / time), 10 launches on the library's stream in "
+                                  "this run (osp_stream_copy_probe)")
+    roof["frac_of_measured"] = roof["achieved"] / copy_gbps if copy_gbps else None
+    for k in roof["kernels"].values():
+        k["frac_of_measured"] = k["GBps"] / copy_gbps if copy_gbps else None
+    return roof
 
 
 def kernel_roofline(infos, n, E):
@@ -542,25 +584,34 @@ def check_sum(got, want, dtype, what):
     return {"sum_C": got, "expected_(1^T A)(B 1)": want, "rel_err": rel}
 
 
-def extra_workload(ctx, name, n, csr, csc, args, np_dtype, tdtype, device, E, stream, steps=3):
-    """One secondary workload, measured the same way as the headline (fewer steps) and checked the same way."""
+def extra_workload(ctx, name, n, csr, csc, args, np_dtype, tdtype, device, E, stream, steps=3, copy_gbps=None, cpu_full=False):
+    """One secondary workload, measured the same way as the headline (fewer steps) and checked the same way.  cpu_full: the
+    CPU reference runs the WHOLE product beside it and the GPU result is compared with it entry by entry."""
     import torch
     torch.cuda.synchronize()   # the operands come from torch kernels on ANOTHER stream than the library's: they must be complete
-    step, _ = make_step(ctx, n, csr, csc, np_dtype, tdtype, device, 0, stream)
+    step, ptrs = make_step(ctx, n, csr, csc, np_dtype, tdtype, device, 0, stream)
     dt, infos = timed(step, steps, 1, torch.cuda.synchronize)
     info = infos[-1]
     chk = check_sum(step(checksum=True)["val_sum_global"], expected_value_sum(n, csr, csc, device), args.dtype, name)
     ms = dt / steps * 1e3
     roof = kernel_roofline(infos, n, E)
     alg = 2 * E * info["partials"] + E * (2 * info["nnz_a"] + info["nnz_c"]) + 8 * (3 * n + 3)
-    return {"ms_per_step": ms, "steps": steps, "value": info["nnz_c"] / (ms * 1e-3), "unit": "nnz/s",
-            "partials_per_s": info["partials"] / (ms * 1e-3), "n": n, "nnz_a": int(info["nnz_a"]), "partials": int(info["partials"]),
-            "nnz_c": int(info["nnz_c"]), "panels": int(info["panels"]), "streamed": bool(stream),
-            "whole_product_GBps_algorithmic": alg / (ms * 1e-3) / 1e9, "whole_product_frac_of_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "phases_ms": {k: float(np.mean([i[k] for i in infos])) for k in ("ms_symbolic", "ms_multiply", "ms_merge", "ms_total")},
-            "kernels": {k: {"GBps": v["GBps"], "frac_of_peak": v["frac_of_peak"], "ms_per_launch": v["ms_per_launch"],
-                            "launches_per_step": v["launches_per_step"]} for k, v in roof["kernels"].items()},
-            "result_check_rel_err": chk["rel_err"]}
+    rec = {"ms_per_step": ms, "steps": steps, "value": info["nnz_c"] / (ms * 1e-3), "unit": "nnz/s",
+           "partials_per_s": info["partials"] / (ms * 1e-3), "n": n, "nnz_a": int(info["nnz_a"]), "partials": int(info["partials"]),
+           "nnz_c": int(info["nnz_c"]), "panels": int(info["panels"]), "streamed": bool(stream),
+           "whole_product_GBps_algorithmic": alg / (ms * 1e-3) / 1e9, "whole_product_frac_of_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "whole_product_frac_of_measured": (alg / (ms * 1e-3) / 1e9 / copy_gbps) if copy_gbps else None,
+           "phases_ms": {k: float(np.mean([i[k] for i in infos])) for k in ("ms_symbolic", "ms_multiply", "ms_merge", "ms_compact", "ms_total")},
+           "kernels": {k: {"GBps": v["GBps"], "frac_of_peak": v["frac_of_peak"], "frac_of_measured": (v["GBps"] / copy_gbps) if copy_gbps else None,
+                           "ms_per_launch": v["ms_per_launch"], "launches_per_step": v["launches_per_step"]} for k, v in roof["kernels"].items()},
+           "result_check_rel_err": chk["rel_err"]}
+    if cpu_full:
+        note(f"{name}: the CPU reference on the whole product ({info['partials']} partial products)")
+        rec["cpu_baseline"], rec["whole_product_parity"] = cpu_baseline(ctx, csc, csr, n, float("inf"), np_dtype, ptrs, full=True)
+        rec["speedup_vs_cpu"] = rec["value"] / rec["cpu_baseline"]["value"]
+        note(f"{name}: CPU {rec['cpu_baseline']['value'] / 1e6:.1f} M nnz/s in {rec['cpu_baseline']['seconds']:.1f} s; whole-product parity: "
+             f"{rec['whole_product_parity']['status']}")
+    return rec
 
 
 _JSON_FD = None
@@ -635,10 +686,12 @@ def library_multi_only(args):
     out = {"value": li["nnz_c"] / (ms * 1e-3), "ms_per_step": ms, "nnz_c": li["nnz_c"], "partials": li["partials"], "result_check": chk,
            "subpanels": li["subpanels"], "bytes_exchanged": li["bytes_exchanged"], "ms_upload_once": li["ms_upload"],
            "devices": [r["device"] for r in li["ranks"]], "gpus_visible": ndev,
-           "ranks": [{k: r[k] for k in ("partials_local", "records_received", "bytes_sent", "nnz_c", "ms_symbolic", "ms_multiply_kernel",
-                                        "ms_merge", "ms_total")} for r in li["ranks"]],
+           "ranks": [{k: r[k] for k in ("partials_local", "records_received", "bytes_sent", "bytes_to", "nnz_c", "ms_symbolic",
+                                        "ms_multiply_kernel", "ms_merge", "ms_exchange", "ms_total", "copy_streams",
+                                        "max_copies_outstanding", "max_copies_in_flight")} for r in li["ranks"]],
            "parallelism": f"k-sharded over {world} ranks inside the library (one process, one host thread per rank): partial products "
-                          "copied GPU to GPU panel by panel behind the multiply, every row range merged as its pieces arrive"}
+                          "copied GPU to GPU behind the multiply, one copy stream per destination (up to N-1 copies per rank in flight), "
+                          "every row range merged on a stream of its own as its pieces arrive"}
     mg.close()
     print(json.dumps(out), flush=True)
 
@@ -727,6 +780,10 @@ def main():
 
     if not use_dist:
         # ================================================= one GPU =================================================
+        # what a plain copy reaches on this box, in this run (the pool's 4 GiB go back before the product sizes its buffers)
+        copy_gbps = ctx.stream_copy_gbps()
+        ctx.trim()
+        note(f"stream copy: {copy_gbps:.0f} GB/s (read + written)")
         step, ptrs = make_step(ctx, n, csr, csc, np_dtype, tdtype, device, args.partial_capacity, args.stream_output)
         dt, infos = timed(step, args.steps, args.warmup, torch.cuda.synchronize)
         info = infos[-1]
@@ -735,7 +792,7 @@ def main():
         note("whole-result check passed")
         nnz_c, P = info["nnz_c"], info["partials"]
         ms_step = dt / args.steps * 1e3
-        roof = kernel_roofline(infos, n, E)
+        roof = add_measured_peak(kernel_roofline(infos, n, E), copy_gbps)
         alg_total = 2 * E * P + E * (2 * nnz_a + nnz_c) + 8 * (3 * n + 3)   # whole product
         out.update({
             "value": nnz_c / (ms_step * 1e-3), "ms_per_step": ms_step,
@@ -743,7 +800,9 @@ def main():
                        "parallelism": "single GPU, output streamed panel by panel (never resident)" if args.stream_output else "single GPU"},
             "gflops": 2 * P / (ms_step * 1e-3) / 1e9, "partials_per_s": P / (ms_step * 1e-3),
             "whole_product": {"algorithmic_bytes": alg_total, "GBps": alg_total / (ms_step * 1e-3) / 1e9,
-                              "frac_of_peak": alg_total / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                              "frac_of_peak": alg_total / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "frac_of_measured": alg_total / (ms_step * 1e-3) / 1e9 / copy_gbps},
+            "library_id": library_id(),
             "phases_ms": {k: float(np.mean([i[k] for i in infos])) for k in ("ms_symbolic", "ms_multiply", "ms_merge", "ms_compact", "ms_total")},
             "panels": info["panels"], "long_rows": info["heavy_rows"], "long_row_partials": info["heavy_partials"],
             # long rows the multiply wrote straight into their column ranges (no split pass), and the ones split afterwards
@@ -785,7 +844,9 @@ def main():
         # workload under profiles/ is attached when there is one; otherwise null
         t = recorded_traffic(workload_name, args.dtype, roof["kernel"])
         if t:
-            roof["traffic"], roof["traffic_source"] = t
+            roof["traffic"], roof["traffic_source"], roof["traffic_library_id"] = t
+            # a recorded figure, not a property of this run: stale when the kernels have changed since the PMC passes
+            roof["traffic_stale"] = (roof["traffic_library_id"] or {}).get("kernel_source_sha16") != out["library_id"]["kernel_source_sha16"]
         default_workload = (args.workload == "rmat" and args.rmat == "mild" and args.scale == 22 and not args.stream_output
                             and args.partial_capacity == 0 and a_mtx is None)
         if args.extras and default_workload and status == 0:
@@ -803,7 +864,10 @@ def main():
                 note(f"extra workload {name}")
                 n2, csr2, csc2 = make()
                 extras[name] = extra_workload(ctx, name, n2, csr2, csc2, args, np_dtype, tdtype, device, E, stream,
-                                              steps={"webgoogle_shape": 5, "rmat22_g500_streamed": 2}.get(name, 3))
+                                              steps={"webgoogle_shape": 5, "rmat22_g500_streamed": 2}.get(name, 3), copy_gbps=copy_gbps,
+                                              cpu_full=bool(args.cpu_baseline) and name in ("webgoogle_shape", "rmat22_uniform"))
+                if extras[name].get("whole_product_parity", {}).get("status", "ok") != "ok":
+                    status = 3
                 del csr2, csc2
                 ctx.trim()
                 torch.cuda.empty_cache()
@@ -872,8 +936,20 @@ def main():
             results["k_library"] = library_multi_child(args, world)
             note(f"library multi-GPU product over {world} ranks: {results['k_library'].get('ms_per_step', results['k_library'])}")
         dist.barrier()
-    head = results["k"] if "k" in results else results[modes[0]]
+    # what the ranks of this job saw of each other: the collective backend's world and every rank's device
+    mine = torch.tensor([dev_index, ndev], device=cdev, dtype=torch.int64)
+    seen = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(seen, mine)
+    fabric = {"backend": args.dist_backend + (" (RCCL)" if args.dist_backend == "nccl" else ""), "world_size": dist.get_world_size(),
+              "rank_devices": [int(x[0]) for x in seen], "gpus_visible_per_rank": [int(x[1]) for x in seen]}
+    torch_head = results["k"] if "k" in results else results[modes[0]]
+    lib = results.get("k_library")
+    # The headline at N > 1 is the library's own k-sharded product (one process, pipelined exchange over one stream per link)
+    # when it ran and its whole-result check passed; otherwise the same decomposition over torch.distributed.  Both stay
+    # under "decompositions".
+    lib_ok = isinstance(lib, dict) and "error" not in lib and "result_check" in lib and lib.get("nnz_c") == torch_head["nnz_c"]
     if rank == 0:
+        head = torch_head
         out.update({
             "value": head["value"], "ms_per_step": head["ms_per_step"],
             "config": {"workload": workload_name, "n": n, "nnz_a": nnz_a, "partials": head["partials"], "nnz_c": head["nnz_c"],
@@ -881,12 +957,25 @@ def main():
             "gflops": 2 * head["partials"] / (head["ms_per_step"] * 1e-3) / 1e9,
             "partials_per_s": head["partials"] / (head["ms_per_step"] * 1e-3),
             "phases_ms": head["rank0_phases_ms"], "roofline": head["rank0_roofline"], "result_check": head["result_check"],
-            # which decomposition `value` is (the other one, when measured, is under decompositions)
+            # which decomposition `value` is (the other ones, when measured, are under decompositions)
             "shard": "k" if head is results.get("k") else modes[0],
             "ms_exchange": head["rank0_phases_ms"].get("ms_exchange"), "ms_final_merge": head["rank0_phases_ms"].get("ms_final_merge"),
             "bytes_sent_per_rank": head.get("bytes_sent_per_rank"),
+            "fabric": fabric,
             "decompositions": results,
         })
+        if lib_ok:
+            out.update({
+                "value": lib["value"], "ms_per_step": lib["ms_per_step"], "shard": "k_library",
+                "gflops": 2 * lib["partials"] / (lib["ms_per_step"] * 1e-3) / 1e9, "partials_per_s": lib["partials"] / (lib["ms_per_step"] * 1e-3),
+                "result_check": lib["result_check"], "ms_exchange": max(r.get("ms_exchange", 0.0) for r in lib["ranks"]),
+                "ms_final_merge": max(r["ms_merge"] for r in lib["ranks"]), "bytes_sent_per_rank": [r["bytes_sent"] for r in lib["ranks"]],
+                "phases_ms": {k: max(r[k] for r in lib["ranks"]) for k in ("ms_symbolic", "ms_multiply_kernel", "ms_merge", "ms_total")},
+                "roofline_note": "roofline: rank 0's kernels in the torch.distributed run of the same decomposition (the library's "
+                                 "multi-GPU product reports per-rank phase times, not per-kernel events)",
+            })
+            out["config"]["parallelism"] = lib["parallelism"]
+            out["config"]["backend"] = "library (hipMemcpyPeerAsync over xGMI, one stream per destination); " + args.dist_backend + " for the comparison run"
         emit(out)
     ctx.close()
     dist.barrier()
@@ -906,7 +995,7 @@ def recorded_traffic(workload, dtype, kernel):
         k = rec.get("kernels", {}).get(kernel)
         if rec.get("workload") == workload and rec.get("dtype") == dtype and k:
             return k["traffic"], (f"{rec.get('source')}: FETCH_SIZE x2 (gfx950 correction for wide reads) + WRITE_SIZE, "
-                                  f"rocprofv3 --pmc, separate passes")
+                                  f"rocprofv3 --pmc, separate passes"), rec.get("library_id")
     return None
 
 

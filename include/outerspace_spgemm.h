@@ -41,7 +41,8 @@
 extern "C" {
 #endif
 
-#define OSP_VERSION 3   /* round of the build: 3 = osp_multi_*, osp_csr_bias_relu, osp_result_coo_rows, direct-row counters */
+#define OSP_VERSION 4   /* round of the build: 3 = osp_multi_*, osp_csr_bias_relu, osp_result_coo_rows, direct-row counters;
+                            4 = per-destination exchange streams (osp_multi_rank_info_t grew) */
 
 typedef enum osp_status {
     OSP_OK = 0,
@@ -239,8 +240,9 @@ int osp_merge_record_parts(osp_context_t ctx, osp_dtype_t dtype, uint64_t M, uin
 /*
  * No reference counterpart (the reference is one process, one thread).  k is cut into one slab per rank, balanced by
  * partial products; rank g holds only columns [k_g, k_g+1) of A and rows [k_g, k_g+1) of B and multiplies them; the
- * partial products travel ONCE, unmerged, to the rank that owns their output row (direct GPU-to-GPU copies, pipelined
- * behind the multiply panel by panel), and every rank merges its row range as the pieces arrive -- parts in rank order =
+ * partial products travel ONCE, unmerged, to the rank that owns their output row (direct GPU-to-GPU copies on one stream per
+ * destination -- up to G-1 per rank in flight, one per link -- pipelined behind the multiply sub-panel by sub-panel), and every
+ * rank merges its row range, on a stream of its own, as the pieces arrive -- parts in rank order =
  * ascending k, the single-GPU summation order: the result is bit-identical to osp_spgemm_csc_csr.  The result stays
  * row-sharded (shard g on device g); osp_multi_result_copy_csr gathers it to the host.
  * devices[] may name an ordinal more than once: logical ranks that share a GPU (how the tests run on a one-GPU box).
@@ -259,6 +261,13 @@ typedef struct osp_multi_rank_info {
     uint64_t bytes_sent;            /* records copied to OTHER ranks */
     uint64_t nnz_c;                 /* entries of its shard */
     float ms_symbolic, ms_multiply_kernel, ms_merge, ms_total;   /* host clock of the rank's thread; kernel time from HIP events */
+    /* the exchange (since version 4): every destination has a copy stream of its own, so a rank's copies run side by side */
+    uint64_t bytes_to[OSP_MULTI_MAX_RANKS];   /* ... of bytes_sent, per destination rank */
+    int copy_streams;               /* exchange streams this rank used: one per destination = one per link */
+    int max_copies_outstanding;     /* most peer copies queued on their streams and not complete at one time (sampled by the host
+                                       after every sub-panel; each only waits for its own piece to be multiplied) */
+    int max_copies_in_flight;       /* most peer copies whose [start, end] overlapped on the device (HIP event timestamps) */
+    float ms_exchange;              /* first copy start -> last copy end */
 } osp_multi_rank_info_t;
 typedef struct osp_multi_info {
     int nranks, subpanels;          /* sub-panels per row range: the granularity of the multiply / copy / merge pipeline */
@@ -303,6 +312,12 @@ int osp_csr_bias_relu(osp_result_t in, const void *bias, osp_memspace_t bias_spa
 /* The row index of every entry of a CSR result (nnz_c values, DEVICE memory of the caller): with the result's colidx /
  * vals arrays that is the COO form osp_spgemm_coo takes, so an activation feeds the next product without leaving the GPU. */
 int osp_result_coo_rows(osp_result_t r, uint32_t *rows_device);
+
+/* ---- measurement aid: what a plain stream reaches on this device ------------------------------------------------------ */
+/* A 16-bytes-per-lane copy of `bytes` bytes, `reps` times on the context's stream; *gbps = (read + written) / time in GB/s.
+ * No reference counterpart in the product path: SURVEY.md 8d asks for "an achievable-stream number on the box" beside the
+ * data-sheet peak (the reference prints its simulated DRAM rate, SimOuterSPACE.cpp:684-686). */
+int osp_stream_copy_probe(osp_context_t ctx, uint64_t bytes, int reps, double *gbps);
 
 /* ---- results --------------------------------------------------------------------------- */
 int osp_result_info(osp_result_t r, osp_result_info_t *info);

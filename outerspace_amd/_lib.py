@@ -68,7 +68,9 @@ class MultiRankInfo(C.Structure):
     """osp_multi_rank_info_t"""
     _fields_ = [("device", C.c_int), ("k_begin", C.c_uint64), ("k_end", C.c_uint64), ("row_begin", C.c_uint64), ("row_end", C.c_uint64),
                 ("partials_local", C.c_uint64), ("records_received", C.c_uint64), ("bytes_sent", C.c_uint64), ("nnz_c", C.c_uint64),
-                ("ms_symbolic", C.c_float), ("ms_multiply_kernel", C.c_float), ("ms_merge", C.c_float), ("ms_total", C.c_float)]
+                ("ms_symbolic", C.c_float), ("ms_multiply_kernel", C.c_float), ("ms_merge", C.c_float), ("ms_total", C.c_float),
+                ("bytes_to", C.c_uint64 * MULTI_MAX_RANKS), ("copy_streams", C.c_int), ("max_copies_outstanding", C.c_int),
+                ("max_copies_in_flight", C.c_int), ("ms_exchange", C.c_float)]
 
 
 class MultiInfo(C.Structure):
@@ -79,7 +81,8 @@ class MultiInfo(C.Structure):
 
     def as_dict(self):
         d = {name: getattr(self, name) for name, _ in self._fields_ if name != "rank"}
-        d["ranks"] = [{n: getattr(self.rank[g], n) for n, _ in MultiRankInfo._fields_} for g in range(self.nranks)]
+        d["ranks"] = [{n: (list(getattr(self.rank[g], n))[:self.nranks] if n == "bytes_to" else getattr(self.rank[g], n))
+                       for n, _ in MultiRankInfo._fields_} for g in range(self.nranks)]
         return d
 
 
@@ -92,6 +95,7 @@ EXPORTS = [
     "osp_merge_csr_parts", "osp_result_info", "osp_result_copy_csr", "osp_result_device_ptrs",
     "osp_result_destroy", "osp_mtx_read", "osp_host_free", "osp_coo_to_compressed_f32",
     "osp_coo_to_compressed_f64", "osp_spgemm_mtx", "osp_result_write_mtx", "osp_csr_bias_relu", "osp_result_coo_rows",
+    "osp_stream_copy_probe",
     "osp_multi_context_create", "osp_multi_context_destroy", "osp_multi_operands_create", "osp_multi_operands_destroy", "osp_spgemm_multi",
     "osp_spgemm_csc_csr_multi", "osp_multi_result_info", "osp_multi_result_shard", "osp_multi_result_copy_csr", "osp_multi_result_destroy",
 ]
@@ -152,6 +156,7 @@ def lib():
         getattr(L, f"osp_coo_to_compressed_{sfx}").argtypes = [i32, u64, u64, vp, vp, vp, vp, vp, vp]
     L.osp_spgemm_mtx.argtypes = [vp, i32, C.c_char_p, C.c_char_p, i32, C.POINTER(Config), C.POINTER(vp)]
     L.osp_result_write_mtx.argtypes = [vp, C.c_char_p]
+    L.osp_stream_copy_probe.argtypes = [vp, u64, i32, C.POINTER(C.c_double)]
     L.osp_multi_context_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
     L.osp_multi_context_destroy.argtypes = [vp]
     L.osp_multi_operands_create.argtypes = [vp, i32, u64, u64, u64, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]

@@ -2142,6 +2142,38 @@ int osp_result_coo_rows(osp_result_t r_, uint32_t *rows_device) {
     OSP_GUARD_END
 }
 
+// ---- what a plain stream reaches on this device (bench.py: roofline.peak_measured) ----
+// 16 bytes per lane, grid-stride, as many workgroups as keep every CU busy: the copy SURVEY.md 8d / BASELINE.md ask to be
+// measured on the box beside the 8 TB/s of the data sheet (the reference prints its simulated DRAM rate,
+// SimOuterSPACE.cpp:684-686).  rate = (bytes read + bytes written) / time.
+__global__ __launch_bounds__(256) void stream_copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
+}
+int osp_stream_copy_probe(osp_context_t ctx_, uint64_t bytes, int reps, double *gbps) {
+    Context *ctx = (Context *)ctx_;
+    if (!ctx || !gbps) return fail(OSP_ERR_ARG, "null argument");
+    if (bytes < 4096 || reps < 1 || reps > 1000) return fail(OSP_ERR_ARG, "bytes >= 4096, 1 <= reps <= 1000");
+    OSP_GUARD_BEGIN
+    OSP_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    Scratch sc(ctx);
+    const uint64_t n = bytes / sizeof(uint4);
+    uint4 *src = sc.get<uint4>(n), *dst = sc.get<uint4>(n);
+    OSP_HIP(hipMemsetAsync(src, 0x5a, n * sizeof(uint4), s));
+    const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ctx->cus * 8);
+    for (int i = 0; i < 2; i++) stream_copy_kernel<<<grid, 256, 0, s>>>(src, dst, n);   // untimed: page tables, clocks
+    EventPair ev;
+    OSP_HIP(hipEventRecord(ev.a, s));
+    for (int i = 0; i < reps; i++) stream_copy_kernel<<<grid, 256, 0, s>>>(src, dst, n);
+    OSP_HIP(hipEventRecord(ev.b, s));
+    OSP_HIP(hipStreamSynchronize(s));
+    OSP_HIP(hipGetLastError());
+    const double ms = ev.ms();
+    *gbps = ms > 0 ? 2.0 * (double)(n * sizeof(uint4)) * reps / (ms * 1e-3) / 1e9 : 0.0;
+    return OSP_OK;
+    OSP_GUARD_END
+}
+
 // ---- several GPUs of one node (osp_multi.h) ----
 int osp_multi_context_create(const int *devices, int ndev, osp_multi_context_t *out) {
     if (!devices || !out) return fail(OSP_ERR_ARG, "null argument");
@@ -2154,10 +2186,17 @@ int osp_multi_context_create(const int *devices, int ndev, osp_multi_context_t *
             if (st) { delete mc; return st; }   // (the message is already set)
             mc->devices.push_back(devices[g]);
             mc->ctx.push_back((Context *)c);
-            hipStream_t cs = nullptr;
+            mc->copy.emplace_back((size_t)ndev, nullptr);
+            mc->mctx.push_back(nullptr);
+            osp_context_t c2 = nullptr;
+            const int st2 = osp_context_create(devices[g], &c2);   // the merge of what arrives: a stream and a pool of its own
+            if (st2) { delete mc; return st2; }
+            mc->mctx.back() = (Context *)c2;
             OSP_HIP(hipSetDevice(devices[g]));
-            OSP_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-            mc->copy.push_back(cs);
+            for (int h = 0; h < ndev; h++) {
+                if (h == g) continue;
+                OSP_HIP(hipStreamCreateWithFlags(&mc->copy[g][h], hipStreamNonBlocking));   // one stream per destination: one per link
+            }
         }
         // direct copies between the GPUs where the hardware allows them (xGMI); without peer access a copy is staged
         // through the host by the runtime, which is slower but correct

@@ -7,16 +7,19 @@
 //     [k_g, k_g+1) of B (osp_multi_operands_create uploads them once).
 //   * every rank runs the symbolic phase of its slab -> records per output row; the per-row counts of all ranks are
 //     summed on rank 0 and the rows are cut into G ranges of equal exchanged volume, each range into R sub-panels.
-//   * PIPELINE.  Rank g multiplies panel by panel -- sub-panel r of the range of rank (g+s) mod G, for r = 0.., s = 0..G-1:
-//     at any time every destination receives from exactly one source, so all links carry traffic -- into one of two send
-//     buffers; a second stream copies the finished panel to its owner (hipMemcpyPeerAsync: the xGMI DMA engines) while
-//     the next panel multiplies.  The owner merges sub-panel r as soon as the G pieces of it have arrived, while the
-//     pieces of sub-panel r+1 are still on their way.  A rank's own rows are multiplied straight into its receive buffer.
-//     Time at G ranks ~ max(multiply + merge of P/G, exchange of (G-1)/G * P/G per rank) instead of their sum.
+//   * PIPELINE.  Rank g multiplies sub-panel by sub-panel: for r = 0.., the piece of sub-panel r it owes every OTHER rank
+//     (destination (g+1) mod G first, so that at any time the ranks start on different destinations) into that
+//     destination's send slot, then its own piece straight into its receive buffer.  Every destination has a copy stream
+//     and two send slots of its own: the piece leaves (hipMemcpyPeerAsync: the xGMI DMA engines) as soon as it is multiplied,
+//     on the link to ITS owner, while the pieces for the other destinations and the next sub-panel multiply -- up to G-1
+//     copies of one rank are in flight at once, one per link.  The owner merges sub-panel r on a stream (and pool) of its
+//     own as soon as its G pieces have arrived, while the later sub-panels are still multiplied and copied.
+//     Time at G ranks ~ max(multiply + merge of P/G, exchange of (G-1)/G * P/G per rank over G-1 links) instead of their sum.
 //   * the merge sums the G pieces of a row in rank order = ascending k, the single-GPU order: bit-identical results.
 // One host thread per rank drives its GPU (the merge's planning reads scalars back and would otherwise serialise the
 // ranks); they meet at a few host barriers and hand each other HIP events.
 #pragma once
+#include <array>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -41,13 +44,16 @@ struct HostBarrier {
 
 struct MultiContext {
     std::vector<int> devices;          // HIP ordinal of every rank (an ordinal may repeat: logical ranks sharing a GPU)
-    std::vector<Context *> ctx;        // one context (stream + pool) per rank
-    std::vector<hipStream_t> copy;     // the rank's exchange stream
+    std::vector<Context *> ctx;        // one context (stream + pool) per rank: symbolic phase, multiply
+    std::vector<Context *> mctx;       // a second one per rank for the merge of what arrives: it runs beside the multiply
+    std::vector<std::vector<hipStream_t>> copy;   // copy[g][h]: the stream of rank g's copies to rank h (one per link)
     ~MultiContext() {
         for (size_t g = 0; g < ctx.size(); g++) {
             if (!ctx[g]) continue;
             (void)hipSetDevice(ctx[g]->device);
-            if (g < copy.size() && copy[g]) { (void)hipStreamSynchronize(copy[g]); (void)hipStreamDestroy(copy[g]); }
+            if (g < copy.size())
+                for (hipStream_t cs : copy[g]) if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
+            if (g < mctx.size() && mctx[g]) osp_context_destroy((osp_context_t)mctx[g]);
             osp_context_destroy((osp_context_t)ctx[g]);
         }
     }
@@ -169,7 +175,7 @@ static void multi_rank_main(MultiContext *mc, const MultiOperands *ops, MultiSha
         catch (const std::exception &e) { sh->fail(OSP_ERR_ALLOC, "rank " + std::to_string(g) + ": " + e.what()); }
     };
     (void)hipSetDevice(ctx->device);
-    hipStream_t s = ctx->stream, cs = mc->copy[g];
+    hipStream_t s = ctx->stream;
     Scratch sc(ctx);
     PhaseTimer tm(s);
     const MultiOperands::Slab &sl = ops->slab[g];
@@ -253,26 +259,34 @@ static void multi_rank_main(MultiContext *mc, const MultiOperands *ops, MultiSha
         OSP_HIP(hipStreamSynchronize(s));
     });
     sh->bar.wait();
-    // ---- E. multiply panel by panel; every finished panel leaves for its owner while the next one multiplies ----
+    // ---- E. multiply sub-panel by sub-panel; every finished piece leaves on the stream of ITS destination ----
     uint64_t bytes_sent = 0;
-    const auto t_mul = std::chrono::steady_clock::now();
-    Part<T> *sendbuf[2] = {nullptr, nullptr};
-    hipEvent_t produced[2] = {nullptr, nullptr}, slot_free[2] = {nullptr, nullptr};
-    bool slot_used[2] = {false, false};
+    std::vector<uint64_t> bytes_to(G, 0);
+    struct Slot { Part<T> *buf = nullptr; hipEvent_t produced = nullptr, copied = nullptr; bool used = false; };
+    std::vector<std::array<Slot, 2>> slots(G);
+    struct CopyRec { hipEvent_t t0 = nullptr, t1 = nullptr; };
+    std::vector<CopyRec> copies;            // start / end of every peer copy (timestamps: how many overlapped)
+    hipEvent_t t_base = nullptr;
+    int max_outstanding = 0;
+    Context *mctx = mc->mctx[g];
     guarded([&] {
-        uint64_t max_send = 1;
-        for (int h = 0; h < G; h++)
-            if (h != g)
-                for (int r = 0; r < R; r++) max_send = std::max(max_send, sh->offs[g][(size_t)h * R + r + 1] - sh->offs[g][(size_t)h * R + r]);
-        if (G > 1)
-            for (int i = 0; i < 2; i++) {
-                sendbuf[i] = sc.get<Part<T>>(max_send);
-                OSP_HIP(hipEventCreateWithFlags(&produced[i], hipEventDisableTiming));
-                OSP_HIP(hipEventCreateWithFlags(&slot_free[i], hipEventDisableTiming));
+        OSP_HIP(hipEventCreate(&t_base));
+        OSP_HIP(hipEventRecord(t_base, s));
+        for (int h = 0; h < G; h++) {
+            if (h == g) continue;
+            uint64_t max_send = 1;
+            for (int r = 0; r < R; r++) max_send = std::max(max_send, sh->offs[g][(size_t)h * R + r + 1] - sh->offs[g][(size_t)h * R + r]);
+            for (int i = 0; i < std::min(R, 2); i++) {
+                slots[h][i].buf = sc.get<Part<T>>(max_send);
+                OSP_HIP(hipEventCreateWithFlags(&slots[h][i].produced, hipEventDisableTiming));
+                OSP_HIP(hipEventCreateWithFlags(&slots[h][i].copied, hipEventDisableTiming));
             }
-        int turn = 0;
-        for (int r = 0; r < R; r++)
-            for (int st = 0; st < G; st++) {
+        }
+        copies.reserve((size_t)G * R);
+        for (int r = 0; r < R; r++) {
+            // the pieces for the other ranks first (their copies start while the rest of the sub-panel multiplies), rank g's
+            // own piece last
+            for (int st = 1; st <= G; st++) {
                 const int h = (g + st) % G;
                 const size_t j = (size_t)h * R + r;
                 const uint64_t r0 = sh->bounds[j], r1 = sh->bounds[j + 1];
@@ -284,16 +298,24 @@ static void multi_rank_main(MultiContext *mc, const MultiOperands *ops, MultiSha
                     if (count) prod.produce(r0, r1, false, base, count, sh->recv[g][g] + dst_off, tm, nullptr, nullptr);
                     OSP_HIP(hipEventRecord(arrive, s));
                 } else {
-                    const int slot = turn++ & 1;
+                    hipStream_t cs = mc->copy[g][h];
                     if (count) {
-                        if (slot_used[slot]) OSP_HIP(hipStreamWaitEvent(s, slot_free[slot], 0));   // the copy out of this buffer has finished
-                        prod.produce(r0, r1, false, base, count, sendbuf[slot], tm, nullptr, nullptr);
-                        OSP_HIP(hipEventRecord(produced[slot], s));
-                        OSP_HIP(hipStreamWaitEvent(cs, produced[slot], 0));
-                        OSP_HIP(hipMemcpyPeerAsync(sh->recv[h][g] + dst_off, mc->ctx[h]->device, sendbuf[slot], ctx->device, count * sizeof(Part<T>), cs));
-                        OSP_HIP(hipEventRecord(slot_free[slot], cs));
-                        slot_used[slot] = true;
+                        Slot &sl2 = slots[h][r & 1];
+                        if (sl2.used) OSP_HIP(hipStreamWaitEvent(s, sl2.copied, 0));   // the copy out of this slot (sub-panel r - 2) has finished
+                        prod.produce(r0, r1, false, base, count, sl2.buf, tm, nullptr, nullptr);
+                        OSP_HIP(hipEventRecord(sl2.produced, s));
+                        OSP_HIP(hipStreamWaitEvent(cs, sl2.produced, 0));
+                        CopyRec cr;
+                        OSP_HIP(hipEventCreate(&cr.t0));
+                        OSP_HIP(hipEventCreate(&cr.t1));
+                        copies.push_back(cr);
+                        OSP_HIP(hipEventRecord(cr.t0, cs));
+                        OSP_HIP(hipMemcpyPeerAsync(sh->recv[h][g] + dst_off, mc->ctx[h]->device, sl2.buf, ctx->device, count * sizeof(Part<T>), cs));
+                        OSP_HIP(hipEventRecord(cr.t1, cs));
+                        OSP_HIP(hipEventRecord(sl2.copied, cs));
+                        sl2.used = true;
                         bytes_sent += count * sizeof(Part<T>);
+                        bytes_to[h] += count * sizeof(Part<T>);
                     }
                     OSP_HIP(hipEventRecord(arrive, cs));
                 }
@@ -303,23 +325,34 @@ static void multi_rank_main(MultiContext *mc, const MultiOperands *ops, MultiSha
                 }
                 sh->arr_cv.notify_all();
             }
+            // copies queued on their streams and not complete (the host runs ahead of the device; each of them only waits
+            // for its own piece to be multiplied)
+            int outstanding = 0;
+            for (const CopyRec &cr : copies) {
+                const hipError_t q = hipEventQuery(cr.t1);
+                if (q == hipErrorNotReady) outstanding++;
+                (void)hipGetLastError();
+            }
+            max_outstanding = std::max(max_outstanding, outstanding);
+        }
     });
     if (sh->failed.load()) sh->arr_cv.notify_all();
-    // ---- F. merge this rank's row range, sub-panel by sub-panel, as the pieces arrive ----
+    // ---- F. merge this rank's row range, sub-panel by sub-panel, as the pieces arrive: on the merge context's stream ----
     Result *res = new Result;
-    res->ctx = ctx;
+    res->ctx = mctx;
     res->dtype = ops->dtype;
     res->info.M = Mh; res->info.N = N; res->info.dtype = ops->dtype;
-    note_variants(ctx, res);
+    note_variants(mctx, res);
     float ms_merge = 0;
     guarded([&] {
+        hipStream_t ms = mctx->stream;
         std::vector<const int64_t *> rps(G);
         std::vector<const void *> recs(G);
         for (int q = 0; q < G; q++) { rps[q] = sh->rp[g][q]; recs[q] = sh->recv[g][q]; }
         std::vector<uint64_t> cuts;   // local rows where a merge panel must end: the sub-panel bounds
         for (int r = 1; r < R; r++) cuts.push_back(sh->bounds[(size_t)g * R + r] - rb0);
         // before a merge panel reads the pieces: every rank's copy of the sub-panel it lies in must have been issued
-        // (host side: the event exists as a recorded event) and must complete before the stream goes on (device side)
+        // (host side: the event exists as a recorded event) and must complete before the merge stream goes on (device side)
         std::function<void(uint64_t, uint64_t)> before = [&](uint64_t r0, uint64_t) {
             int r = 0;
             while (r + 1 < R && sh->bounds[(size_t)g * R + r + 1] - rb0 <= r0) r++;
@@ -328,23 +361,48 @@ static void multi_rank_main(MultiContext *mc, const MultiOperands *ops, MultiSha
                 sh->arr_cv.wait(l, [&] { return sh->arrived[(size_t)g * R + r] >= G || sh->failed.load(); });
             }
             if (sh->failed.load()) throw Error(OSP_ERR_HIP, "another rank failed");
-            for (int q = 0; q < G; q++) OSP_HIP(hipStreamWaitEvent(s, sh->ev[((size_t)g * G + q) * R + r], 0));
+            for (int q = 0; q < G; q++) OSP_HIP(hipStreamWaitEvent(ms, sh->ev[((size_t)g * G + q) * R + r], 0));
         };
         const auto t0 = std::chrono::steady_clock::now();
         osp_config_t c2 = cfg;
         c2.validate = 0;
-        merge_record_parts_impl<T>(ctx, res, Mh, N, G, rps.data(), recs.data(), OSP_DEVICE, c2, &cuts, &before);
+        merge_record_parts_impl<T>(mctx, res, Mh, N, G, rps.data(), recs.data(), OSP_DEVICE, c2, &cuts, &before);
         ms_merge = ms_since(t0);
     });
     // everything this rank queued -- its copies to others included -- is complete before its buffers go away
-    (void)hipStreamSynchronize(cs);
+    for (int h = 0; h < G; h++) if (h != g) (void)hipStreamSynchronize(mc->copy[g][h]);
     (void)hipStreamSynchronize(s);
+    (void)hipStreamSynchronize(mctx->stream);
     const float ms_total = ms_since(t_begin);
+    // how many of this rank's copies overlapped in time, and the span of its exchange (HIP event timestamps)
+    int max_in_flight = 0;
+    float ms_exchange = 0;
+    if (t_base && !copies.empty() && !sh->failed.load()) {
+        std::vector<std::pair<float, int>> edges;
+        float first = 0, last = 0;
+        bool any = false;
+        for (const CopyRec &cr : copies) {
+            float a = 0, b = 0;
+            if (hipEventElapsedTime(&a, t_base, cr.t0) != hipSuccess || hipEventElapsedTime(&b, t_base, cr.t1) != hipSuccess) { (void)hipGetLastError(); continue; }
+            edges.push_back({a, +1});
+            edges.push_back({b, -1});
+            first = any ? std::min(first, a) : a;
+            last = any ? std::max(last, b) : b;
+            any = true;
+        }
+        std::sort(edges.begin(), edges.end(), [](const std::pair<float, int> &x, const std::pair<float, int> &y) { return x.first < y.first || (x.first == y.first && x.second < y.second); });
+        int cur = 0;
+        for (auto &e : edges) { cur += e.second; max_in_flight = std::max(max_in_flight, cur); }
+        ms_exchange = any ? last - first : 0.f;
+    }
     sh->bar.wait();   // nobody releases a receive buffer another rank may still be writing
     for (void *p : pooled) ctx->release(p);
     for (int h = 0; h < G; h++)
         for (int r = 0; r < R; r++) { hipEvent_t e = sh->ev[((size_t)h * G + g) * R + r]; if (e) (void)hipEventDestroy(e); }
-    for (int i = 0; i < 2; i++) { if (produced[i]) (void)hipEventDestroy(produced[i]); if (slot_free[i]) (void)hipEventDestroy(slot_free[i]); }
+    for (auto &pair : slots)
+        for (Slot &sl2 : pair) { if (sl2.produced) (void)hipEventDestroy(sl2.produced); if (sl2.copied) (void)hipEventDestroy(sl2.copied); }
+    for (CopyRec &cr : copies) { if (cr.t0) (void)hipEventDestroy(cr.t0); if (cr.t1) (void)hipEventDestroy(cr.t1); }
+    if (t_base) (void)hipEventDestroy(t_base);
     out->shard[g] = res;
     osp_multi_rank_info_t &ri = out->info.rank[g];
     ri.device = ctx->device;
@@ -353,12 +411,16 @@ static void multi_rank_main(MultiContext *mc, const MultiOperands *ops, MultiSha
     ri.partials_local = sh->P[g];
     ri.records_received = recv_total;
     ri.bytes_sent = bytes_sent;
+    for (int h = 0; h < G; h++) ri.bytes_to[h] = bytes_to[h];
+    ri.copy_streams = G - 1;
+    ri.max_copies_outstanding = max_outstanding;
+    ri.max_copies_in_flight = max_in_flight;
+    ri.ms_exchange = ms_exchange;
     ri.nnz_c = res->info.nnz_c;
     ri.ms_symbolic = ms_symbolic;
     ri.ms_multiply_kernel = tm.total(PH_MUL_K);
     ri.ms_merge = ms_merge;
     ri.ms_total = ms_total;
-    (void)t_mul;
 }
 
 template <class T>

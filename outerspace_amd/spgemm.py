@@ -224,10 +224,18 @@ class Context:
                                              C.byref(cfg), C.byref(h)))
         return CsrResult(self, h)
 
-    def spgemm_coo_device(self, dtype, M, K, N, nnz_a, a_ptrs, nnz_b, b_ptrs, *, partial_capacity=0):
+    def stream_copy_gbps(self, nbytes=2 << 30, reps=10):
+        """What a plain 16-bytes-per-lane copy reaches on this device, read + written bytes per second in GB/s
+        (``osp_stream_copy_probe``): the measured roof beside the data sheet's."""
+        g = C.c_double()
+        _lib.check(_lib.lib().osp_stream_copy_probe(self._h, int(nbytes), int(reps), C.byref(g)))
+        return g.value
+
+    def spgemm_coo_device(self, dtype, M, K, N, nnz_a, a_ptrs, nnz_b, b_ptrs, *, partial_capacity=0, k_range=None):
         """``spgemm_coo`` on DEVICE arrays: a_ptrs / b_ptrs = (rows, cols, vals) addresses (u32, u32, dtype), entries in any
-        order.  ``result.info['ms_ingest']`` is the device time of the two COO -> CSC / CSR conversions."""
-        cfg = self._config(True, partial_capacity, None)
+        order.  ``result.info['ms_ingest']`` is the device time of the two COO -> CSC / CSR conversions.  ``k_range``
+        restricts the PRODUCT behind the conversions to a slab of k (the conversions always take the whole operands)."""
+        cfg = self._config(True, partial_capacity, k_range)
         h = C.c_void_p()
         _lib.check(_lib.lib().osp_spgemm_coo(self._h, _DT[np.dtype(dtype)], M, K, N, int(nnz_a), *[C.c_void_p(int(p)) for p in a_ptrs],
                                              int(nnz_b), *[C.c_void_p(int(p)) for p in b_ptrs], _lib.OSP_DEVICE, C.byref(cfg), C.byref(h)))

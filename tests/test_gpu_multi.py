@@ -38,11 +38,44 @@ def test_multi_gpu_product_is_bit_identical(port, nranks, preset, scale, dt):
         assert sum(r["nnz_c"] for r in ranks) == info["nnz_c"]
         if nranks > 1:
             assert info["bytes_exchanged"] > 0 and all(r["bytes_sent"] > 0 for r in ranks)
+            # one copy stream per destination; what went where adds up, nothing is "sent" to oneself
+            for g, r in enumerate(ranks):
+                assert r["copy_streams"] == nranks - 1 and sum(r["bytes_to"]) == r["bytes_sent"] and r["bytes_to"][g] == 0
+                assert r["max_copies_in_flight"] >= 1 and r["max_copies_outstanding"] >= 1 and r["ms_exchange"] > 0
+            # what rank g sent to rank h is what h received from others, in total
+            assert sum(r["bytes_sent"] for r in ranks) == info["bytes_exchanged"]
             # slabs balanced by partial products
             assert max(r["partials_local"] for r in ranks) < 2.5 * want["partials"] / nranks
         # the loaded slabs stay resident: a second product gives the same result
         info2, (rowptr2, colidx2, v2) = mg.multiply()
         assert np.array_equal(rowptr2, rowptr) and np.array_equal(colidx2, colidx) and np.array_equal(v2, v)
+
+
+def test_multi_gpu_exchange_fans_out(monkeypatch):
+    """The exchange of osp_multi.h: every destination has a copy stream and send slots of its own, so the G-1 pieces of a
+    sub-panel are all queued -- each waiting only for its own piece to be multiplied -- before the host looks again.  On one
+    GPU (logical ranks) the copies are device-to-device and as fast as the multiply, so whether their DMA intervals overlap
+    is only asserted where the ranks sit on different devices.  Result against the one-GPU product, bit for bit."""
+    import torch
+    from outerspace_amd import spgemm as S
+    monkeypatch.setenv("OSP_MULTI_SUBPANELS", "4")
+    n, rows, cols, vals = gen.rmat_coo(16, 16, "mild", seed=7)
+    acsc, bcsr = S.coo_to_csc(n, rows, cols, vals), S.coo_to_csr(n, rows, cols, vals)
+    with S.Context(0) as ctx:
+        one = ctx.spgemm_csc_csr(n, n, n, *acsc, *bcsr)
+        want = (one.rowptr.copy(), one.colidx.copy(), one.vals.copy())
+        one.close()
+    G = 4
+    with S.MultiGpu(_devices(G)) as mg:
+        info, (rowptr, colidx, v) = mg.spgemm_csc_csr(n, n, n, *acsc, *bcsr)
+        assert np.array_equal(rowptr, want[0]) and np.array_equal(colidx, want[1]) and np.array_equal(v, want[2])
+        assert info["subpanels"] == 4
+        for g, r in enumerate(info["ranks"]):
+            assert r["copy_streams"] == G - 1
+            assert all(b > 0 for h, b in enumerate(r["bytes_to"]) if h != g)
+            assert r["max_copies_outstanding"] >= min(G - 1, 2), info["ranks"]
+            if torch.cuda.device_count() >= 2:
+                assert r["max_copies_in_flight"] >= min(G - 1, 2), info["ranks"]
 
 
 @pytest.mark.parametrize("subpanels", ["1", "7"])

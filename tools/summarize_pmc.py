@@ -44,7 +44,9 @@ def main(fetch_csv, write_csv, bench_json, out_prefix, title):
     bench = json.loads(open(bench_json).read().strip().splitlines()[-1])
     alg = {k: v["algorithmic_bytes_per_launch"] for k, v in bench["roofline"]["kernels"].items()}
     names = sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, 0) + write.get(k, 0)))
-    out = {"workload": bench["config"]["workload"], "dtype": bench["dtype"], "source": out_prefix + ".md", "kernels": {}}
+    # library_id: which kernels these counters belong to (bench.py compares it with the library it runs: roofline.traffic_stale)
+    out = {"workload": bench["config"]["workload"], "dtype": bench["dtype"], "source": out_prefix + ".md", "library_id": bench.get("library_id"),
+           "kernels": {}}
     with open(out_prefix + ".md", "w") as f:
         f.write(f"# {title}\n\nTwo separate passes (`rocprofv3 --pmc FETCH_SIZE --kernel-trace`, `--pmc WRITE_SIZE --kernel-trace`); "
                 "counter unit KiB.  gfx950: FETCH_SIZE counts wide coalesced reads at half their size "
