@@ -505,7 +505,7 @@ def library_id():
 def add_measured_peak(roof, copy_gbps):
     """Both fractions: of the data sheet's 8 TB/s and of what a plain copy reached on this box in this run."""
     roof["peak_measured"] = copy_gbps
-    roof["peak_measured_what"] = ("16-bytes-per-lane copy of 2 GiB (read + written bytes / time), 10 launches on the library's stream in "
+    roof["peak_measured_what"] = ("16-bytes-per-lane copy of 2 GiB, one workgroup per 4 KB (read + written bytes / time), 10 launches on the library's stream in "
                                   "this run (osp_stream_copy_probe)")
     roof["frac_of_measured"] = roof["achieved"] / copy_gbps if copy_gbps else None
     for k in roof["kernels"].values():

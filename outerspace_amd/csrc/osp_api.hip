@@ -629,7 +629,7 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
     // without a sort.  It bites for rows with more than one product per 8 columns of B (kSplitTarget = 256 per 2048 columns).  (Until late in round 3 the cap
     // was never below kSplitRowBits, i.e. without effect for N < 2^20: a product with dense output rows -- 32768^2, 634
     // entries per row -- sorted 512 ranges of 64 columns per row, 370 ms; with 16 ranges of 2048 columns it takes 197.)
-    const int bits_cap = getenv("OSP_SPLIT_BITS_CAP") ? atoi(getenv("OSP_SPLIT_BITS_CAP")) : std::max(colbits - kDenseBits, 1);
+    const int bits_cap = std::max(colbits - kDenseBits, 1);
     uint64_t ndcell = 0, tot[6] = {0, 0, 0, 0, 0, 0};
     for (int attempt = 0; attempt < 2; attempt++) {
         split_params_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(pl.p0.long_rows, nlong, row_off, colbits, row_max, bits_cap, ds ? ds->rowfirst : nullptr,
@@ -1104,8 +1104,18 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     { Gather g(s); g.add(&nnz_total, (const uint64_t *)out_nnz + npanels); g.add(&aflag, (const uint32_t *)abort_word); g.wait(); }
     check_abort(aflag);
     res->info.nnz_c = nnz_total;
-    // give memory back when the product compressed a lot (copy is small next to the P-sized work)
-    if (Context::bucket(std::max<uint64_t>(nnz_total, 1) * sizeof(T)) * 10 < Context::bucket(std::max<uint64_t>(cap_c, 1) * sizeof(T)) * 7) {
+    // The arrays were sized by the bound sum_i min(U_i, N); a product that compresses leaves their tails unused.  Copying the
+    // result into arrays of its exact size gives that memory back -- at the price of reading and writing all of C once more
+    // (the cage15 shape: 5 of 48 ms for 11.6 GB of tails).  So the copy is made only where the tails are worth it: more than a
+    // tenth of the device's memory (or OSP_COMPACT_MIN_WASTE bytes; 0 = always, as until round 3).  Below that the result
+    // keeps its bound-sized arrays until it is destroyed, and they go back to the pool whole.
+    const uint64_t waste = (Context::bucket(std::max<uint64_t>(cap_c, 1) * sizeof(T)) - Context::bucket(std::max<uint64_t>(nnz_total, 1) * sizeof(T))) +
+                           (Context::bucket(std::max<uint64_t>(cap_c, 1) * sizeof(uint32_t)) - Context::bucket(std::max<uint64_t>(nnz_total, 1) * sizeof(uint32_t)));
+    const uint64_t min_waste = getenv("OSP_COMPACT_MIN_WASTE") ? strtoull(getenv("OSP_COMPACT_MIN_WASTE"), nullptr, 10) : (uint64_t)(total_b / 10);
+    res->info.output_slack_bytes = waste;
+    if (Context::bucket(std::max<uint64_t>(nnz_total, 1) * sizeof(T)) * 10 < Context::bucket(std::max<uint64_t>(cap_c, 1) * sizeof(T)) * 7 &&
+        waste >= min_waste) {
+        res->info.output_slack_bytes = 0;
         tm.begin(PH_COMPACT);
         uint32_t *nc = (uint32_t *)ctx->alloc(std::max<uint64_t>(nnz_total, 1) * sizeof(uint32_t));
         T *nv = (T *)ctx->alloc(std::max<uint64_t>(nnz_total, 1) * sizeof(T));
@@ -2143,12 +2153,9 @@ int osp_result_coo_rows(osp_result_t r_, uint32_t *rows_device) {
 }
 
 // ---- what a plain stream reaches on this device (bench.py: roofline.peak_measured) ----
-// 16 bytes per lane, grid-stride, as many workgroups as keep every CU busy: the copy SURVEY.md 8d / BASELINE.md ask to be
+// 16 bytes per lane, one workgroup per 4 KB: the copy SURVEY.md 8d / BASELINE.md ask to be
 // measured on the box beside the 8 TB/s of the data sheet (the reference prints its simulated DRAM rate,
 // SimOuterSPACE.cpp:684-686).  rate = (bytes read + bytes written) / time.
-__global__ __launch_bounds__(256) void stream_copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint64_t n) {
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
-}
 int osp_stream_copy_probe(osp_context_t ctx_, uint64_t bytes, int reps, double *gbps) {
     Context *ctx = (Context *)ctx_;
     if (!ctx || !gbps) return fail(OSP_ERR_ARG, "null argument");
@@ -2157,19 +2164,28 @@ int osp_stream_copy_probe(osp_context_t ctx_, uint64_t bytes, int reps, double *
     OSP_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     Scratch sc(ctx);
-    const uint64_t n = bytes / sizeof(uint4);
-    uint4 *src = sc.get<uint4>(n), *dst = sc.get<uint4>(n);
-    OSP_HIP(hipMemsetAsync(src, 0x5a, n * sizeof(uint4), s));
-    const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ctx->cus * 8);
-    for (int i = 0; i < 2; i++) stream_copy_kernel<<<grid, 256, 0, s>>>(src, dst, n);   // untimed: page tables, clocks
-    EventPair ev;
-    OSP_HIP(hipEventRecord(ev.a, s));
-    for (int i = 0; i < reps; i++) stream_copy_kernel<<<grid, 256, 0, s>>>(src, dst, n);
-    OSP_HIP(hipEventRecord(ev.b, s));
-    OSP_HIP(hipStreamSynchronize(s));
-    OSP_HIP(hipGetLastError());
-    const double ms = ev.ms();
-    *gbps = ms > 0 ? 2.0 * (double)(n * sizeof(uint4)) * reps / (ms * 1e-3) / 1e9 : 0.0;
+    const uint64_t n = bytes / sizeof(u32x4);
+    u32x4 *src = sc.get<u32x4>(n), *dst = sc.get<u32x4>(n);
+    OSP_HIP(hipMemsetAsync(src, 0x5a, n * sizeof(u32x4), s));
+    if (n > 0xffffffffull * 256ull) return fail(OSP_ERR_ARG, "probe buffer too large");
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    double best = 0;
+    for (int nt = 0; nt < 2; nt++) {   // plain and non-temporal accesses: the better of the two is the measured roof
+        for (int i = 0; i < 2; i++) {   // untimed: page tables, clocks
+            if (nt) stream_copy_kernel<true><<<grid, 256, 0, s>>>(src, dst, n); else stream_copy_kernel<false><<<grid, 256, 0, s>>>(src, dst, n);
+        }
+        EventPair ev;
+        OSP_HIP(hipEventRecord(ev.a, s));
+        for (int i = 0; i < reps; i++) {
+            if (nt) stream_copy_kernel<true><<<grid, 256, 0, s>>>(src, dst, n); else stream_copy_kernel<false><<<grid, 256, 0, s>>>(src, dst, n);
+        }
+        OSP_HIP(hipEventRecord(ev.b, s));
+        OSP_HIP(hipStreamSynchronize(s));
+        OSP_HIP(hipGetLastError());
+        const double ms = ev.ms();
+        if (ms > 0) best = std::max(best, 2.0 * (double)(n * sizeof(u32x4)) * reps / (ms * 1e-3) / 1e9);
+    }
+    *gbps = best;
     return OSP_OK;
     OSP_GUARD_END
 }

@@ -74,4 +74,17 @@ __global__ void csr_expand_rows_kernel(const int64_t *__restrict__ rowptr, uint6
     for (int64_t p = rowptr[r] + lane_id(); p < rowptr[r + 1]; p += kWave) rows[p] = (uint32_t)r;
 }
 
+// ---- what a plain stream reaches (osp_stream_copy_probe) ----
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ __launch_bounds__(256) void stream_copy_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, uint64_t n) {
+    // one 16-byte element per lane, one workgroup per 4 KB: the shape that reaches the highest rate here (tools/bench_copy:
+    // 6.2 TB/s; persistent grid-stride loops with 1-8 loads in flight per lane 4.5-5.5, hipMemcpyAsync 4.8).  NT: non-temporal
+    // accesses (the form the library's own streams use for what is written once and read much later)
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (NT) __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]);
+    else dst[i] = src[i];
+}
+
 }  // namespace osp

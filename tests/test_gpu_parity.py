@@ -646,6 +646,30 @@ def test_lattice_shape_vs_oracle(ctx, port, tname):
     res.close()
 
 
+@pytest.mark.parametrize("min_waste", ["0", "default"])
+def test_compressing_product_keeps_or_copies_its_bound_sized_arrays(port, monkeypatch, min_waste):
+    """A product that compresses leaves the tails of its bound-sized arrays unused.  The copy to exact-size arrays is made only
+    where the tails are worth it (more than a tenth of the device's memory; OSP_COMPACT_MIN_WASTE=0: always): same result
+    either way, and the info says which happened (output_slack_bytes, ms_compact)."""
+    import torch
+    from outerspace_amd import spgemm as S
+    if min_waste != "default":
+        monkeypatch.setenv("OSP_COMPACT_MIN_WASTE", min_waste)
+    dev = torch.device("cuda", 0)
+    n, csr, csc = _bench_module().cage15_device(5, dev, torch.float64, side=24)
+    host = [t.cpu().numpy() for t in (*csc, *csr)]
+    host = [a.view(np.uint32) if a.dtype == np.int32 else a for a in host]
+    want = port.spgemm(n, n, n, *host)
+    with S.Context(0) as c2:
+        res = c2.spgemm_csc_csr_device(np.float64, n, n, n, [t.data_ptr() for t in (*csc, *csr)])
+        assert np.array_equal(res.rowptr, want["rowptr"]) and np.array_equal(res.colidx, want["colidx"]) and np.array_equal(res.vals, want["vals"])
+        if min_waste == "0":
+            assert res.info["output_slack_bytes"] == 0 and res.info["ms_compact"] > 0
+        else:
+            assert res.info["output_slack_bytes"] > 0 and res.info["ms_compact"] == 0
+        res.close()
+
+
 def test_rmat22_full_size_properties_and_slab_parity(ctx, port):
     """configs[2] at its full size (R-MAT scale 22, edge factor 16, (a,b,c,d) = (.45,.22,.22,.11), seed 1: nnz 67 M,
     P = 1.19e10, nnz(C) = 1.15e10 -- 138 GB of CSR, far beyond what the oracle can form):
