@@ -115,6 +115,9 @@ typedef struct osp_result_info {
     uint32_t rank_atomic;       /* 1: stable radix ranks from the return order of LDS atomics, 0: from ballot matching   */
     uint32_t dense_atomic;      /* 1: dense segments summed by LDS floating-point atomics, 0: by ballot ranks and rounds */
                                 /* (both variants are exact; a context picks them by a self-test)         */
+    uint64_t hub_rows;          /* since version 4: rows beyond the one-workgroup planner (> 128 K partial products) that the multiply
+                                   wrote straight into uniform column blocks (no stretch split) */
+    uint64_t hub_partials;      /* partial products in those rows */
     uint64_t output_slack_bytes;/* since version 4: bytes of the result's colidx / vals allocations beyond nnz_c entries (they are
                                    sized by the bound sum_i min(U_i, N) before the merge; copied to exact size only when the
                                    slack exceeds a tenth of the device's memory -- 0 after such a copy) */

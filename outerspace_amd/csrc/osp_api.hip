@@ -500,8 +500,10 @@ template <class T> struct Producer {
     // enqueue kernels that fill stage[0 .. row_off[r1]-row_off[r0]) for rows [r0,r1)
     // (cells / qstage: the plan and the second buffer of the panel's direct rows, osp_kernels.h store_direct; null
     // when the panel has none)
+    // (hub: cells and run table of the panel's hub rows, osp_kernels.h "HUB rows"; null when the panel has none)
     virtual void produce(uint64_t r0, uint64_t r1, bool whole, uint64_t base, uint64_t count,
-                         Part<T> *stage, PhaseTimer &tm, const uint32_t *cells = nullptr, Part<T> *qstage = nullptr) = 0;
+                         Part<T> *stage, PhaseTimer &tm, const uint32_t *cells = nullptr, Part<T> *qstage = nullptr,
+                         const HubArgs *hub = nullptr) = 0;
 };
 
 // ---- rows of partial products -> merged rows -------------------------------------------------------
@@ -562,6 +564,12 @@ struct DirectSrc {
     const uint32_t *rowfirst; const uint64_t *off; const uint32_t *bs; const uint32_t *perm; const uint32_t *b_colidx;
     uint64_t *chunk_off;
     uint64_t direct_max;
+    // hub rows (osp_split.h, hub_plan_kernel): B's pointer array for the run table, which is made when the first panel with hub
+    // rows asks for it and lives in `keep` as long as the product
+    const int64_t *b_rowptr = nullptr;
+    uint64_t K = 0, nnz_b = 0;
+    Scratch *keep = nullptr;
+    mutable HubTables hub{};
 };
 
 // What is decided about a panel BEFORE its partial products exist (plan_panel) and used after the multiply (merge_panel).
@@ -581,6 +589,7 @@ template <class T> struct PanelPlan {
     uint8_t *vfirst = nullptr;
     uint32_t *vcol0 = nullptr, *vcol1 = nullptr;
     uint32_t *cells = nullptr;        // direct rows: range tables and (chunk, range) cells
+    HubArgs hub{};                    // hub rows: (chunk, run) cells and B's run table; cells == nullptr: the panel has none
     explicit PanelPlan(Context *c) : sc(c) {}
 };
 
@@ -630,10 +639,26 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
     // was never below kSplitRowBits, i.e. without effect for N < 2^20: a product with dense output rows -- 32768^2, 634
     // entries per row -- sorted 512 ranges of 64 columns per row, 370 ms; with 16 ranges of 2048 columns it takes 197.)
     const int bits_cap = std::max(colbits - kDenseBits, 1);
+    // Hub rows: with a chunk table at hand the rows beyond the one-workgroup planner are written by the multiply as well, into
+    // 2^hub_b uniform column blocks (no narrower than a dense accumulator, no more than the stretch split's 4096), instead of
+    // being moved by the stretch split afterwards.  It needs the lane order of LDS atomics (the context's self-test) and B's
+    // run table; OSP_HUB=0 keeps the stretch split (debugging aid, A/B timing).
+    const int hub_b_want = std::min(kSplitMaxBits, bits_cap);
+    const bool hub_env = !(getenv("OSP_HUB") && atoi(getenv("OSP_HUB")) == 0);
+    int hub_b = 0;
     uint64_t ndcell = 0, tot[6] = {0, 0, 0, 0, 0, 0};
-    for (int attempt = 0; attempt < 2; attempt++) {
+    // ... and it pays only where such rows hold a good part of the panel's products: the multiply of a panel with hub rows is
+    // the instantiation that knows their descriptors (74 registers instead of 68) for ALL its products, and the plan has fixed
+    // costs.  Measured (round 4): Graph500 scale 22 streamed 3.48 -> 3.23 s, scale 20 387 -> 368 ms with them (stretch rows:
+    // more than half of the products); R-MAT-22 "mild" (2 %) 236 -> 250 ms.  OSP_HUB_MIN_SHARE moves the threshold.
+    const double hub_min_share = getenv("OSP_HUB_MIN_SHARE") ? atof(getenv("OSP_HUB_MIN_SHARE")) : 0.2;
+    bool hub_decided = false;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        const bool hub_possible = ds && ds->b_rowptr && ds->keep && ctx->rank_atomic && hub_env;
+        if (!hub_possible) hub_b = 0;
         split_params_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(pl.p0.long_rows, nlong, row_off, colbits, row_max, bits_cap, ds ? ds->rowfirst : nullptr,
-                                                                 ds ? ds->direct_max : 0ull, kCap, pl.hbits, pl.hmode, pl.nstretch, nseg, nhist, ncellh);
+                                                                 ds ? ds->direct_max : 0ull, kCap, pl.hbits, pl.hmode, pl.nstretch, nseg, nhist, ncellh,
+                                                                 hub_b);
         zero_async(s, {{totals, 6 * sizeof(uint64_t)}});
         mode_totals_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(pl.p0.long_rows, nlong, row_off, pl.hmode, totals);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{pl.nstretch}, nlong, pl.blkbase, pl.hscan_tmp, s);
@@ -651,8 +676,14 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
         }
         // the cells of a panel are addressed with 32 bits (and are device memory beside the staging buffers): a panel whose
         // plan would not fit splits its long rows after the multiply instead
-        if (!ds || ndcell < 0xffffffffull) break;
-        ds = nullptr;
+        if (ds && ndcell >= 0xffffffffull) { ds = nullptr; hub_b = 0; continue; }
+        // first look at the panel: do its stretch rows hold enough of it to be planned as hub rows?  (once more, with their blocks)
+        if (hub_possible && !hub_decided && hub_b == 0 && pl.nblocks && (double)tot[3 + kModeStretch] >= hub_min_share * (double)count) {
+            hub_decided = true;
+            hub_b = hub_b_want;
+            continue;
+        }
+        break;
     }
     for (int m = 0; m < 3; m++) { pl.mode_rows[m] = tot[m]; pl.mode_partials[m] = tot[3 + m]; }
     if (pl.nh >= 0xffffffffull) throw Error(OSP_ERR_CAPACITY, "long rows of one panel exceed 2^32 partial products");
@@ -696,6 +727,47 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
 #endif
         res->info.direct_plan_launches++;
         dbg_sync(s, "plan of the direct rows");
+    }
+    if (hub_b && pl.nblocks) {
+        // ---- hub rows: B's run table (once per product), per-job block totals, ONE scan for the segment offsets, cells ----
+        if (!ds->hub.sx) {
+            Scratch &keep = *ds->keep;
+            const uint64_t nb = ds->nnz_b;
+            Scratch tmp(ctx);
+            uint8_t *rowstart = tmp.get<uint8_t>(nb + 4);
+            uint32_t *sx = keep.get<uint32_t>(nb + 1), *runstart = keep.get<uint32_t>(nb + 1);
+            uint32_t *scan_tmp = tmp.get<uint32_t>(scan_scratch_entries(nb + 1));
+            OSP_HIP(hipMemsetAsync(rowstart, 0, nb + 4, s));
+            hub_rowstart_kernel<<<grid_for(ds->K, 256), 256, 0, s>>>(ds->b_rowptr, ds->K, rowstart);
+            const int sh = colbits - hub_b;
+            const HubRunFlag flag{rowstart, ds->b_colidx, sh};
+            device_exclusive_scan<HubRunFlag, uint32_t>(flag, nb, sx, scan_tmp, s);
+            compact_flagged_kernel<HubRunFlag><<<grid_for(nb, 256), 256, 0, s>>>(flag, sx, nb, 0, runstart);
+            hub_runstart_end_kernel<<<1, 1, 0, s>>>(sx + nb, runstart, (uint32_t)nb);
+            OSP_HIP(hipStreamSynchronize(s));   // (tmp goes back to the pool; everything that read it is done)
+            ds->hub.sx = sx; ds->hub.runstart = runstart; ds->hub.sh = sh;
+        }
+        tm.begin(PH_PLAN_K);
+        uint64_t *jobruns = sc.get<uint64_t>(pl.nblocks + 1);
+        uint64_t *jobscan_tmp = sc.get<uint64_t>(scan_scratch_entries(pl.nblocks + 1));
+        const size_t hub_lds = sizeof(uint32_t) << hub_b;
+        hub_plan_kernel<false><<<(unsigned)pl.nblocks, kHubThreads, hub_lds, s>>>(pl.p0.long_rows, nlong, pl.blkbase, pl.hbase, pl.hbits, pl.nstretch, row_off,
+                                                                           ds->rowfirst, ds->off, ds->bs, ds->perm, ds->b_colidx, ds->hub, pl.ghist,
+                                                                           pl.hoff, jobruns, nullptr, nullptr, nullptr);
+        device_exclusive_scan<LoadU32, uint32_t>(LoadU32{pl.ghist}, pl.ncell, pl.ghist, pl.ghist_tmp, s);
+        device_exclusive_scan<LoadU64, uint64_t>(LoadU64{jobruns}, pl.nblocks, jobruns, jobscan_tmp, s);
+        const uint64_t ncells = d2h(jobruns + pl.nblocks, s);
+        if (ncells >= (1ull << 40)) throw Error(OSP_ERR_CAPACITY, "hub rows: too many runs in one panel");
+        uint32_t *hcells = sc.get<uint32_t>(ncells);
+        hub_plan_kernel<true><<<(unsigned)pl.nblocks, kHubThreads, hub_lds, s>>>(pl.p0.long_rows, nlong, pl.blkbase, pl.hbase, pl.hbits, pl.nstretch, row_off,
+                                                                          ds->rowfirst, ds->off, ds->bs, ds->perm, ds->b_colidx, ds->hub, pl.ghist,
+                                                                          pl.hoff, nullptr, jobruns, hcells, ds->chunk_off);
+        tm.end(PH_PLAN_K);
+        pl.hub.cells = hcells;
+        pl.hub.sx = ds->hub.sx;
+        res->info.hub_rows += pl.mode_rows[kModeStretch];
+        res->info.hub_partials += pl.mode_partials[kModeStretch];
+        dbg_sync(s, "plan of the hub rows");
     }
 }
 
@@ -744,7 +816,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
             res->info.split_partials += pl.mode_partials[kModeSplitRow];
             dbg_sync(s, "split: one-workgroup rows");
         }
-        if (nblocks) {  // longer rows: one workgroup per 4096-entry stretch, offsets from a device-wide scan
+        if (nblocks && !pl.hub.cells) {  // longer rows: one workgroup per 4096-entry stretch, offsets from a device-wide scan
             split_count_kernel<<<(unsigned)nblocks, kSplitThreads, 0, s>>>(p0.long_rows, nlong, blkbase, hbase, hbits, nstretch, io.row_off,
                                                                          base, colbits, (const char *)io.stage, (uint32_t)sizeof(Part<T>), ghist);
             device_exclusive_scan<LoadU32, uint32_t>(LoadU32{ghist}, ncell, ghist, ghist_tmp, s);
@@ -1056,7 +1128,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
             plan_panel<T>(ctx, res, tm, plan, d_row_off, r0, r1, base, count, colbits, ds);
             tm.end(PH_MERGE);
             tm.begin(PH_MUL);
-            if (count) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm, plan.cells, plan.qstage);
+            if (count) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm, plan.cells, plan.qstage, plan.hub.cells ? &plan.hub : nullptr);
             tm.end(PH_MUL);
             tm.begin(PH_MERGE);
             OSP_HIP(hipMemsetAsync(cells, 0, 2 * sizeof(uint64_t), s));
@@ -1089,7 +1161,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         plan_panel<T>(ctx, res, tm, plan, d_row_off, r0, r1, base, count, colbits, ds);
         tm.end(PH_MERGE);
         tm.begin(PH_MUL);
-        if (count) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm, plan.cells, plan.qstage);
+        if (count) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm, plan.cells, plan.qstage, plan.hub.cells ? &plan.hub : nullptr);
         tm.end(PH_MUL);
         // ---- merge ----
         tm.begin(PH_MERGE);
@@ -1142,7 +1214,7 @@ template <class T> struct OuterProducer : Producer<T> {
     int64_t *a_start; uint32_t *a_cnt; uint64_t *prod; uint64_t *prod_off; uint64_t *scan_tmp;
     bool nothing_staged = false;  // row-wise variant and no row is longer than a tile: the tile kernel does it all
     void produce(uint64_t r0, uint64_t r1, bool whole, uint64_t base, uint64_t count, Part<T> *stage,
-                 PhaseTimer &tm, const uint32_t *cells, Part<T> *qstage) override {
+                 PhaseTimer &tm, const uint32_t *cells, Part<T> *qstage, const HubArgs *hub = nullptr) override {
         if (nothing_staged) return;
         hipStream_t s = ctx->stream;
         const uint64_t nk = k1 - k0;
@@ -1152,12 +1224,15 @@ template <class T> struct OuterProducer : Producer<T> {
         const uint64_t nblocks = (count + kMulPerBlock - 1) / kMulPerBlock;
         dbg_sync(s, "panel columns + scan");
         tm.begin(PH_MUL_K);
-        if (cells)
-            multiply_kernel<T, true><<<(unsigned)nblocks, kMulThreads, 0, s>>>(a_vals, b_colidx, b_vals, b_rowptr, chunk_off, e0,
-                                                                             a_start, a_cnt, prod_off, k0, nk, count, base, stage, cells, qstage);
+        if (hub && hub->cells)
+            multiply_kernel<T, 2><<<(unsigned)nblocks, kMulThreads, 0, s>>>(a_vals, b_colidx, b_vals, b_rowptr, chunk_off, e0,
+                                                                          a_start, a_cnt, prod_off, k0, nk, count, base, stage, cells, qstage, *hub);
+        else if (cells)
+            multiply_kernel<T, 1><<<(unsigned)nblocks, kMulThreads, 0, s>>>(a_vals, b_colidx, b_vals, b_rowptr, chunk_off, e0,
+                                                                          a_start, a_cnt, prod_off, k0, nk, count, base, stage, cells, qstage);
         else
-            multiply_kernel<T, false><<<(unsigned)nblocks, kMulThreads, 0, s>>>(a_vals, b_colidx, b_vals, b_rowptr, chunk_off, e0,
-                                                                              a_start, a_cnt, prod_off, k0, nk, count, base, stage, nullptr, nullptr);
+            multiply_kernel<T, 0><<<(unsigned)nblocks, kMulThreads, 0, s>>>(a_vals, b_colidx, b_vals, b_rowptr, chunk_off, e0,
+                                                                          a_start, a_cnt, prod_off, k0, nk, count, base, stage, nullptr, nullptr);
         tm.end(PH_MUL_K);
         dbg_sync(s, "multiply");
         res->info.multiply_launches++;
@@ -1169,7 +1244,7 @@ template <class T> struct PartsProducer : Producer<T> {
     const int64_t *const *d_rowptrs; const uint32_t *const *d_colidxs; const T *const *d_valss;
     int nparts;
     const uint64_t *row_off;
-    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &, const uint32_t *, Part<T> *) override {
+    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &, const uint32_t *, Part<T> *, const HubArgs *) override {
         const uint64_t nr = r1 - r0;
         parts_scatter_kernel<T><<<grid_for(nr * kWave, 256), 256, 0, ctx->stream>>>(d_rowptrs, d_colidxs, d_valss, nparts,
                                                                                     r0, r1, row_off, base, stage);
@@ -1182,7 +1257,7 @@ template <class T> struct RecordPartsProducer : Producer<T> {
     int nparts;
     const uint64_t *row_off;
     const std::function<void(uint64_t, uint64_t)> *before = nullptr;   // called with the panel's rows before its records are read
-    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &, const uint32_t *, Part<T> *) override {
+    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &, const uint32_t *, Part<T> *, const HubArgs *) override {
         if (before) (*before)(r0, r1);
         const uint64_t nr = r1 - r0;
         parts_scatter_rec_kernel<T><<<grid_for(nr * kWave, 256), 256, 0, ctx->stream>>>(d_rowptrs, d_recs, nparts, r0, r1, row_off, base, stage);
@@ -1393,7 +1468,10 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         // (the product proper reads P together with the size of the result, merge_pipeline: one stream round trip less)
         if (partials_only || rowwise || row_sharded) P = d2h(offs_sorted + nnz, s);
         else P = kPartialsOnDevice;
-        if (direct) dsrc = DirectSrc{rowfirst, offs_sorted, bs_sorted, perm, b_colidx, chunk_off, direct_max};
+        if (direct) {
+            dsrc = DirectSrc{rowfirst, offs_sorted, bs_sorted, perm, b_colidx, chunk_off, direct_max};
+            dsrc.b_rowptr = b_rowptr; dsrc.K = K; dsrc.nnz_b = (uint64_t)nnz_b; dsrc.keep = &sc;
+        }
         if (rowwise) {
             ct = ChunkTable<T>{offs_sorted, bs_sorted, perm, rowfirst, a_vals + e0, b_colidx, b_vals, (uint32_t)rw_cap, 1u};
             uint32_t *flag_scan = ss.get<uint32_t>(M + 1);

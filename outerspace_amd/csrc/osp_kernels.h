@@ -308,6 +308,21 @@ constexpr uint64_t kDirectBit = 1ull << 63;
 __device__ __forceinline__ uint64_t direct_desc(uint32_t rowbase, uint32_t celloff, uint32_t sh) {
     return kDirectBit | ((uint64_t)(sh & 31u) << 58) | ((uint64_t)(celloff & 0x3ffffffu) << 32) | (uint64_t)rowbase;
 }
+// HUB rows (round 4): a row too long for the planner above (more than 128 K partial products: the hub rows of a skewed
+// matrix) used to be moved range by range AFTER the multiply by the stretch split (osp_split.h): two more reads and one more
+// write of every record.  Such a row's ranges are uniform blocks of 2^sh columns, so which of its entries a chunk puts into
+// which block depends on B's row alone: a table made once per product numbers the RUNS of every B row (maximal sequences of
+// entries inside one block; sx[e] = runs that start before entry e, over all of B) and the hub planner (hub_plan_kernel) stores
+// one cell per (chunk, run): the run's place in the second buffer minus the index of its first entry.  The chunk's descriptor
+// carries the marker 31 where a direct row's carries its shift, and the first cell's index in the low 58 bits; a product
+// (chunk, l-th entry of B's row at position p) goes to record  hubcells[first cell + (sx[p + 1] - 1 - sx[row start])] + l.
+constexpr uint64_t kHubCellMask = (1ull << 58) - 1ull;
+__device__ __forceinline__ uint64_t hub_desc(uint64_t first_cell) { return kDirectBit | (31ull << 58) | (first_cell & kHubCellMask); }
+__device__ __forceinline__ bool is_hub_desc(uint64_t desc) { return ((uint32_t)(desc >> 58) & 31u) == 31u; }   // (of a direct descriptor that is not kChunkSkip)
+struct HubArgs {
+    const uint32_t *cells = nullptr;   // one per (chunk of a hub row, run of its B row)
+    const uint32_t *sx = nullptr;      // runs of B that start before entry e (nnz(B) + 1 entries)
+};
 // A record of a direct row: OSP_NT_DIRECT=1 streams it past L2 like the chunk-major records; 0 leaves it to L2, where the
 // runs of consecutive chunks of a hub row -- adjacent in the range, written close in time -- can meet in one line.
 #ifndef OSP_NT_DIRECT
@@ -321,9 +336,18 @@ __device__ __forceinline__ void store_direct_part(Part<T> *p, uint32_t col, T va
     *p = Part<T>{col, val};
 #endif
 }
-template <class T>
-__device__ __forceinline__ void store_direct(const uint32_t *__restrict__ cells, Part<T> *__restrict__ qstage, uint64_t desc, uint32_t l,
-                                             uint32_t bc, T v) {
+// (bs: where the chunk's B row starts in B's arrays; the entry is bs + l)
+template <class T, int MODE>
+__device__ __forceinline__ void store_direct(const uint32_t *__restrict__ cells, const HubArgs &hub, Part<T> *__restrict__ qstage, uint64_t desc,
+                                             uint64_t bs, uint32_t l, uint32_t bc, T v) {
+    if constexpr (MODE == 2) {
+        if (is_hub_desc(desc)) {
+            const uint32_t ri = hub.sx[bs + l + 1] - 1u - hub.sx[bs];
+            const uint32_t cell = hub.cells[(desc & kHubCellMask) + ri];
+            store_direct_part(&qstage[(uint32_t)(cell + l)], bc, v);
+            return;
+        }
+    }
     const uint32_t *rb = cells + (uint32_t)desc;
     const uint32_t sh = (uint32_t)(desc >> 58) & 31u, co = (uint32_t)(desc >> 32) & 0x3ffffffu;
     const uint32_t rg = reinterpret_cast<const uint8_t *>(rb)[bc >> sh];
@@ -336,10 +360,13 @@ __device__ __forceinline__ void store_direct(const uint32_t *__restrict__ cells,
 // dependent loads per entry (range of the column, cell of the range); written one chunk after the other, every store
 // waits for both, and that latency -- not bandwidth -- bounds the kernel (R-MAT-22: 10.1 -> 17.3 ms per launch).  Here the
 // loads of all QU chunks go out together, branch-free (a chunk that is not direct reads a word of `safe` and ignores it).
-template <class T, int QU, bool DIRECT>
-__device__ __forceinline__ void chunk_dests(const uint32_t *__restrict__ cells, const void *safe, Part<T> *__restrict__ stage,
+// MODE 2: the launch has hub rows too; ri = the entry's run number inside its B row (the same for every chunk of the column)
+template <class T, int QU, int MODE>
+__device__ __forceinline__ void chunk_dests(const uint32_t *__restrict__ cells, const HubArgs &hub, uint32_t ri, const void *safe,
+                                            Part<T> *__restrict__ stage,
                                             Part<T> *__restrict__ qstage, const uint64_t (&off)[QU], uint32_t lp, uint32_t ld,
                                             uint32_t bc, Part<T> *(&dst)[QU], bool (&dir)[QU]) {
+    constexpr bool DIRECT = MODE != 0;
     if constexpr (!DIRECT) {   // a launch without direct rows: every chunk has a plain staging offset
 #pragma unroll
         for (int i = 0; i < QU; i++) { dir[i] = false; dst[i] = &stage[off[i] + lp]; }
@@ -347,12 +374,14 @@ __device__ __forceinline__ void chunk_dests(const uint32_t *__restrict__ cells, 
     }
     const uint32_t *rb[QU];
     uint32_t rg[QU], delta[QU];
+    bool hubc[QU];
 #pragma unroll
     for (int i = 0; i < QU; i++) {
         dir[i] = (off[i] & kDirectBit) && off[i] != kChunkSkip;   // (wave-uniform)
-        rb[i] = dir[i] ? cells + (uint32_t)off[i] : reinterpret_cast<const uint32_t *>(safe);
+        hubc[i] = MODE == 2 && dir[i] && is_hub_desc(off[i]);
+        rb[i] = (dir[i] && !hubc[i]) ? cells + (uint32_t)off[i] : reinterpret_cast<const uint32_t *>(safe);
         const uint32_t sh = (uint32_t)(off[i] >> 58) & 31u;
-        rg[i] = reinterpret_cast<const uint8_t *>(rb[i])[dir[i] ? bc >> sh : 0u];
+        rg[i] = reinterpret_cast<const uint8_t *>(rb[i])[(dir[i] && !hubc[i]) ? bc >> sh : 0u];
 #ifdef OSP_EXP_EXTRA_GATHER   // experiment only: one more gather of the same kind per store (is the kernel bound by its gathers?)
         {
             const uint32_t extra = reinterpret_cast<const uint8_t *>(rb[i])[dir[i] ? (bc >> sh) ^ 1u : 0u];
@@ -363,7 +392,9 @@ __device__ __forceinline__ void chunk_dests(const uint32_t *__restrict__ cells, 
 #pragma unroll
     for (int i = 0; i < QU; i++) {
         const uint32_t co = (uint32_t)(off[i] >> 32) & 0x3ffffffu;
-        delta[i] = rb[i][dir[i] ? co + rg[i] : 0u];
+        const uint32_t *p = rb[i] + ((dir[i] && !hubc[i]) ? co + rg[i] : 0u);
+        if constexpr (MODE == 2) { if (hubc[i]) p = hub.cells + ((off[i] & kHubCellMask) + ri); }   // one cell per (chunk, run of B's row)
+        delta[i] = *p;
     }
 #pragma unroll
     for (int i = 0; i < QU; i++) dst[i] = dir[i] ? &qstage[(uint32_t)(delta[i] + ld)] : &stage[off[i] + lp];
@@ -376,13 +407,16 @@ __device__ __forceinline__ void chunk_dests(const uint32_t *__restrict__ cells, 
 // is written with consecutive lanes on consecutive addresses.
 // DIRECT: the launch has direct rows (descriptors among the chunk offsets); without them the kernel is instantiated without
 // that code (64 registers instead of 68: one more wave per SIMD, which the products of short rows notice)
-template <class T, bool DIRECT = true>
+// MODE: 0 = no direct rows in the launch, 1 = direct rows, 2 = direct rows and hub rows (descriptors with the hub marker)
+template <class T, int MODE = 1>
 __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
     const T *__restrict__ a_vals, const uint32_t *__restrict__ b_colidx, const T *__restrict__ b_vals,
     const int64_t *__restrict__ b_rowptr, const uint64_t *__restrict__ chunk_off, int64_t e0,
     const int64_t *__restrict__ a_start, const uint32_t *__restrict__ a_cnt,
     const uint64_t *__restrict__ prod_off, uint64_t k0, uint64_t nk, uint64_t total, uint64_t base,
-    Part<T> *__restrict__ stage, const uint32_t *__restrict__ cells = nullptr, Part<T> *__restrict__ qstage = nullptr) {
+    Part<T> *__restrict__ stage, const uint32_t *__restrict__ cells = nullptr, Part<T> *__restrict__ qstage = nullptr,
+    const HubArgs hub = HubArgs{}) {
+    constexpr bool DIRECT = MODE != 0;
     const unsigned lane = lane_id();
     const uint64_t wv = (uint64_t)blockIdx.x * (kMulThreads / kWave) + (threadIdx.x >> 6);
     const uint64_t ws = wv * kMulPerWave;
@@ -444,7 +478,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                         const uint32_t bc = b_colidx[bsx + l];
                         const T pv = a_vals[e] * b_vals[bsx + l];
                         if (raw != kChunkSkip) {
-                            if (DIRECT && (raw & kDirectBit)) store_direct(cells, qstage, raw, l, bc, pv);
+                            if (DIRECT && (raw & kDirectBit)) store_direct<T, MODE>(cells, hub, qstage, raw, bsx, l, bc, pv);
                             else stream_store_part(&stage[raw - base + l], bc, pv);
                         }
                     }
@@ -484,7 +518,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                 const uint64_t xe = min(b, pbeg + (uint64_t)a_cnt[kk] * wp) - pbeg, xin = x - pbeg;
                 const uint64_t tj0 = xin / wp, tj1 = (xe - 1) / wp;
                 const uint32_t tla = (uint32_t)(xin - tj0 * wp), tlb = (uint32_t)(xe - tj1 * wp);
-                uint32_t bc[PER];
+                uint32_t bc[PER], ri[PER];
                 T bv[PER];
 #pragma unroll
                 for (uint32_t u = 0; u < PER; u++) {
@@ -492,6 +526,8 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                     const uint64_t src = bs + (uint64_t)pnl * W + min(lrel, wp - 1);   // clamped: the loads go out together
                     bc[u] = b_colidx[src];
                     bv[u] = b_vals[src];
+                    ri[u] = 0;
+                    if constexpr (MODE == 2) ri[u] = hub.sx[src + 1] - 1u - hub.sx[bs];   // the entry's run inside B's row (hub rows)
                 }
                 for (uint64_t jb = tj0; jb <= tj1; jb += kWave) {
                     const uint64_t jm = jb + lane;
@@ -523,7 +559,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                             const uint32_t lrel = u * kWave + lane;
                             Part<T> *dst[QU];
                             bool dir[QU];
-                            chunk_dests<T, QU, DIRECT>(cells, chunk_off, stage, qstage, off, lrel, pnl * W + lrel, bc[u], dst, dir);
+                            chunk_dests<T, QU, MODE>(cells, hub, ri[u], chunk_off, stage, qstage, off, lrel, pnl * W + lrel, bc[u], dst, dir);
 #pragma unroll
                             for (int i = 0; i < QU; i++)
                                 if (lrel >= lo[i] && lrel < hi[i]) {
@@ -551,8 +587,9 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                 for (uint32_t l0 = 0; l0 < nb; l0 += kWave) {
                     const uint32_t l = l0 + lane;
                     const bool in = l < nb;
-                    uint32_t bc = 0; T bv = 0;
+                    uint32_t bc = 0, ri = 0; T bv = 0;
                     if (in) { bc = b_colidx[bs + l]; bv = b_vals[bs + l]; }
+                    if constexpr (MODE == 2) { if (in) ri = hub.sx[bs + l + 1] - 1u - hub.sx[bs]; }   // the entry's run inside B's row (hub rows)
                     constexpr int QU = OSP_MUL_QU_MID;   // chunks whose destinations are formed together (chunk_dests)
                     for (uint32_t q = 0; q < cj; q += QU) {
                         uint64_t off[QU];
@@ -569,7 +606,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                             ok[i] = in && off[i] != kChunkSkip && !(j == j0 && l < la) && !(j == j1 && l >= lb);
                         }
                         bool dir[QU];
-                        chunk_dests<T, QU, DIRECT>(cells, chunk_off, stage, qstage, off, l, l, bc, dst, dir);
+                        chunk_dests<T, QU, MODE>(cells, hub, ri, chunk_off, stage, qstage, off, l, l, bc, dst, dir);
 #pragma unroll
                         for (int i = 0; i < QU; i++)
                             if (ok[i]) { if (dir[i]) store_direct_part(dst[i], bc, av[i] * bv); else stream_store_part(dst[i], bc, av[i] * bv); }
@@ -591,7 +628,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                     const uint64_t e = as + j;
                     const uint64_t raw = chunk_off[e - (uint64_t)e0];
                     if (raw != kChunkSkip) {
-                        if (DIRECT && (raw & kDirectBit)) store_direct(cells, qstage, raw, l, bc, a_vals[e] * bv);
+                        if (DIRECT && (raw & kDirectBit)) store_direct<T, MODE>(cells, hub, qstage, raw, bs, l, bc, a_vals[e] * bv);
                         else stream_store_part(&stage[raw - base + l], bc, a_vals[e] * bv);
                     }
                 }

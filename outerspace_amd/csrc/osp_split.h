@@ -77,9 +77,13 @@ constexpr uint64_t kDirectRowCells = 1ull << 19;  // (chunk, range) cells of ONE
 // direct_max partial products that one workgroup could split are planned as direct rows instead: nseg = an upper bound
 // of their ranges (consecutive ranges of the greedy grouping together exceed a tile, hence <= 2U/cap + 1 of them),
 // ncell = words of their block in the cell array.
+// hub_b != 0: the rows that are left to the stretch split are HUB rows instead -- written by the multiply into 2^hub_b uniform
+// column blocks (hub_plan_kernel below); they keep the stretch rows' bookkeeping (jobs of kSplitJob products, one histogram
+// column per job), only with the same number of blocks for every such row: the run table of B is made for ONE block width.
 __global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *row_off, int colbits,
                                     uint64_t row_max, int bits_cap, const uint32_t *rowfirst, uint64_t direct_max, uint32_t cap,
-                                    uint8_t *hbits, uint8_t *hmode, uint32_t *nstretch, uint32_t *nseg, uint64_t *nhist, uint64_t *ncell) {
+                                    uint8_t *hbits, uint8_t *hmode, uint32_t *nstretch, uint32_t *nseg, uint64_t *nhist, uint64_t *ncell,
+                                    int hub_b = 0) {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= nheavy) return;
     const uint64_t U = row_off[rows[h] + 1] - row_off[rows[h]];
@@ -100,6 +104,7 @@ __global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const
     const bool direct = rowfirst != nullptr && b <= kSplitRowBits && (!big || capped) && U <= dmax && nranges <= (uint64_t)kDirectMaxRanges &&
                         nc * nranges <= kDirectRowCells;
     const uint32_t ns = (big && !direct) ? (uint32_t)((U + kSplitJob - 1) / kSplitJob) : 0u;  // 0 stretches = one-workgroup row
+    if (ns && hub_b) b = hub_b;
     hbits[h] = (uint8_t)b;
     hmode[h] = direct ? kModeDirect : big ? kModeStretch : kModeSplitRow;
     nstretch[h] = ns;
@@ -844,6 +849,103 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
             chunk_off[perm[c0 + cb + cl]] = direct_desc((uint32_t)cellbase[h], lutw + (cb + cl) * Ta, (uint32_t)sh);
         __syncthreads();   // the block's cells and descriptors have been read
         OSP_PLAN_MARK(5);   // prefixes, cells and descriptors out
+    }
+}
+// ---- hub rows: the plan the multiply phase writes them by -----------------------------------------------------------------
+// (what a hub row is and what the multiply does with the cells: osp_kernels.h, "HUB rows")
+// The run table of B for blocks of 2^sh columns, made once per product: flag(e) = entry e starts a run (first entry of its row,
+// or another block than the entry before it); sx = exclusive scan of the flags; runstart[g] = first entry of run g.
+__global__ void hub_rowstart_kernel(const int64_t *b_rowptr, uint64_t K, uint8_t *rowstart) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K && b_rowptr[k + 1] > b_rowptr[k]) rowstart[b_rowptr[k]] = 1;
+}
+struct HubRunFlag {
+    const uint8_t *rowstart;
+    const uint32_t *col;
+    int sh;
+    __device__ uint32_t operator()(uint64_t e) const { return (rowstart[e] || (col[e] >> sh) != (col[e - 1] >> sh)) ? 1u : 0u; }   // (rowstart[0] is set)
+};
+__global__ void hub_runstart_end_kernel(const uint32_t *nruns_p, uint32_t *runstart, uint32_t nnz) { runstart[*nruns_p] = nnz; }
+struct HubTables {
+    const uint32_t *sx = nullptr;         // runs that start before entry e: nnz(B) + 1 entries
+    const uint32_t *runstart = nullptr;   // first entry of every run, and nnz(B) behind the last
+    int sh = 0;                           // block width: 2^sh columns
+};
+// One WAVE per job of a hub row (the stretch rows' jobs: job st of a row = the chunks whose records start inside the row's
+// products [st, st + 1) * kSplitJob).  The job's runs -- chunk after chunk in ascending k, a chunk's runs in column order: the
+// order the records of a block must have -- are walked 64 at a time: lane q holds chunk q's first run and run count, a lane
+// finds the chunk of flat run x by bisecting the prefix of the counts.
+//   CELLS = false  per-block totals of the job -> ghist[hbase + block * nst + st] (the stretch split's histogram layout, so the
+//                  segment offsets come out of the same scan and split_vrows_kernel), and the job's number of runs;
+//   CELLS = true   ghist holds the scanned offsets: every run's place is what ONE LDS atomic on its block's running offset
+//                  returns -- lanes hitting the same block get their old values in ascending lane order (the property the radix
+//                  ranks rest on, self-tested per context; without it the panel keeps the stretch split) -- and goes, minus
+//                  the index of the run's first entry, into the chunk's cells; the chunk's descriptor goes to chunk_off.
+constexpr int kHubThreads = kWave;
+template <bool CELLS>
+__global__ __launch_bounds__(kHubThreads) void hub_plan_kernel(
+    const uint32_t *__restrict__ rows, uint32_t nheavy, const uint64_t *__restrict__ blkbase, const uint64_t *__restrict__ hbase,
+    const uint8_t *__restrict__ hbits, const uint32_t *__restrict__ nstretch, const uint64_t *__restrict__ row_off,
+    const uint32_t *__restrict__ rowfirst, const uint64_t *__restrict__ ct_off, const uint32_t *__restrict__ ct_bs,
+    const uint32_t *__restrict__ perm, const uint32_t *__restrict__ b_colidx, const HubTables ht, uint32_t *__restrict__ ghist,
+    const uint64_t *__restrict__ hoff, uint64_t *__restrict__ jobruns, const uint64_t *__restrict__ jobcell, uint32_t *__restrict__ cells,
+    uint64_t *__restrict__ chunk_off) {
+    extern __shared__ uint32_t hist[];   // 2^hub_b running offsets (dynamic: 8 KB for 2048 blocks -- 20 jobs in flight per CU)
+    const unsigned lane = lane_id();
+    const uint32_t h = (uint32_t)(upper_bound_dev(blkbase, 0, (uint64_t)nheavy + 1, (uint64_t)blockIdx.x) - 1);
+    const uint32_t st = (uint32_t)(blockIdx.x - blkbase[h]), nst = nstretch[h];
+    const uint32_t nseg = 1u << hbits[h];
+    const uint32_t row = rows[h];
+    const uint64_t hb = hbase[h];
+    // the job's chunks: those whose records start in [jbeg, jend) (absolute staging offsets; the last job takes the rest)
+    const uint64_t jbeg = row_off[row] + (uint64_t)st * kSplitJob, jend = st + 1 == nst ? ~0ull : jbeg + (uint64_t)kSplitJob;
+    const uint32_t c0 = rowfirst[row], c1 = rowfirst[row + 1];
+    const uint32_t ta = (uint32_t)lower_bound_dev(ct_off, (uint64_t)c0, (uint64_t)c1, jbeg);
+    const uint32_t tb = jend == ~0ull ? c1 : (uint32_t)lower_bound_dev(ct_off, (uint64_t)ta, (uint64_t)c1, jend);
+    if (CELLS) {
+        const uint32_t qrow = (uint32_t)hoff[h] - ghist[hb];
+        for (uint32_t d = lane; d < nseg; d += kWave) hist[d] = qrow + ghist[hb + (uint64_t)d * nst + st];
+    } else {
+        for (uint32_t d = lane; d < nseg; d += kWave) hist[d] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint64_t done = 0;   // runs of the job's earlier chunk batches
+    const uint64_t cell0 = CELLS ? jobcell[blockIdx.x] : 0ull;
+    for (uint32_t t0 = ta; t0 < tb; t0 += kWave) {
+        const uint32_t t = t0 + lane;
+        uint32_t bs = 0, g0 = 0, nr = 0;
+        if (t < tb) {
+            bs = ct_bs[t];
+            const uint32_t nb = (uint32_t)(ct_off[t + 1] - ct_off[t]);
+            if (nb) { g0 = ht.sx[bs]; nr = ht.sx[(uint64_t)bs + nb] - g0; }
+        }
+        const uint32_t incl = wave_incl_scan(nr), pre = incl - nr;
+        const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (CELLS && t < tb) chunk_off[perm[t]] = hub_desc(cell0 + done + pre);
+        for (uint32_t x0 = 0; x0 < T; x0 += kWave) {
+            const uint32_t x = x0 + lane;
+            uint32_t lo = 0, hi = kWave;   // last lane whose runs start at or before x (lanes without runs never win)
+#pragma unroll
+            for (int step = 0; step < 6; step++) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((uint32_t)__shfl((int)pre, (int)mid) <= x) lo = mid; else hi = mid;
+            }
+            const uint32_t xr = x - (uint32_t)__shfl((int)pre, (int)lo);
+            const uint32_t g = (uint32_t)__shfl((int)g0, (int)lo) + xr;
+            const uint32_t cbs = (uint32_t)__shfl((int)bs, (int)lo);
+            if (x < T) {
+                const uint32_t e0 = ht.runstart[g], e1 = ht.runstart[g + 1];
+                const uint32_t blk = b_colidx[e0] >> ht.sh;
+                const uint32_t old = atomicAdd(&hist[blk], e1 - e0);   // (lanes in flat run order: the order inside a block)
+                if (CELLS) cells[cell0 + done + x] = old - (e0 - cbs);
+            }
+        }
+        done += T;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (!CELLS) {
+        for (uint32_t d = lane; d < nseg; d += kWave) ghist[hb + (uint64_t)d * nst + st] = hist[d];
+        if (lane == 0) jobruns[blockIdx.x] = done;
     }
 }
 }  // namespace osp

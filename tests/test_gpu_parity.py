@@ -1015,6 +1015,53 @@ def test_hub_segments_dense_accumulation(ctx, port, monkeypatch, dt):
     assert_same(got, want)
 
 
+@pytest.mark.parametrize("hub", ["1", "0"])
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_hub_rows_written_by_the_multiply(port, monkeypatch, _ctx_shared, hub, dt):
+    """Rows beyond the one-workgroup planner (here: beyond OSP_SPLIT_ROW_MAX products) are hub rows: the multiply writes them
+    into uniform column blocks from one cell per (chunk, run of B's row) -- hub_plan_kernel -- instead of the stretch split
+    moving them afterwards (OSP_HUB=0).  Graph500 skew (hub row x hub column: long runs), a row fed by thousands of one-entry
+    chunks (runs of length one), empty chunks in between, several panels, a k range: all bit for bit against the oracle."""
+    from outerspace_amd import spgemm as S
+    monkeypatch.setenv("OSP_HUB", hub)
+    monkeypatch.setenv("OSP_HUB_MIN_SHARE", "0")   # (by default only panels whose products are mostly in such rows plan them this way)
+    monkeypatch.setenv("OSP_SPLIT_ROW_MAX", "3000")
+    monkeypatch.setenv("OSP_DIRECT_MAX", "3000")
+    c = _ctx_shared
+    c.algorithm = "outer"
+    n, rows, cols, vals = gen.rmat_coo(13, 16, "g500", seed=5, dtype=dt)
+    # B: the same pattern with its columns spread over 2^20 (with few columns every long row is a "dense" direct row instead)
+    N = n * 128
+    bcols = (cols.astype(np.uint64) * 128 + (rows.astype(np.uint64) * 31 + cols.astype(np.uint64) * 17) % 128).astype(np.uint32)
+    for kw in ({}, {"partial_capacity": 300000}, {"k_range": (100, 5000)}):
+        got, want = run_both(c, port, n, n, N, (rows, cols, vals), (rows, bcols, vals), dt, **kw)
+        assert_same(got, want)
+        if hub == "1":
+            assert got.info["hub_rows"] > 0 and got.info["hub_partials"] > 0, got.info
+        else:
+            assert got.info["hub_rows"] == 0
+    # one output row fed by 40 000 chunks of one or two entries each (and some of no entry at all), spread over all columns
+    rng = np.random.default_rng(23)
+    M, K, N = 3, 40000, 70000
+    a = (np.concatenate([np.zeros(K, np.uint32), np.full(50, 2, np.uint32)]), np.concatenate([np.arange(K, dtype=np.uint32), np.arange(50, dtype=np.uint32) * 7]),
+         rng.uniform(0.5, 1.5, K + 50).astype(dt))
+    nb = rng.integers(0, 3, K)
+    b_rows = np.repeat(np.arange(K, dtype=np.uint32), nb)
+    b_cols = rng.integers(0, N, len(b_rows)).astype(np.uint32)
+    keep = np.ones(len(b_rows), bool)
+    keep[1:] = (b_rows[1:] != b_rows[:-1]) | (b_cols[1:] != b_cols[:-1])
+    order = np.lexsort((b_cols, b_rows))
+    b_rows, b_cols = b_rows[order], b_cols[order]
+    keep = np.ones(len(b_rows), bool)
+    keep[1:] = (b_rows[1:] != b_rows[:-1]) | (b_cols[1:] != b_cols[:-1])
+    b_rows, b_cols = b_rows[keep], b_cols[keep]
+    b = (b_rows, b_cols, rng.uniform(-1, 1, len(b_rows)).astype(dt))
+    got, want = run_both(c, port, M, K, N, a, b, dt)
+    assert_same(got, want)
+    if hub == "1":
+        assert got.info["hub_rows"] == 1
+
+
 @pytest.mark.parametrize("direct_max", [None, "0", "5000", "40000"])
 def test_direct_rows_written_by_the_multiply(port, monkeypatch, _ctx_shared, direct_max):
     """Long rows that one workgroup could split are written straight into their column ranges by the multiply phase
