@@ -45,9 +45,11 @@ def main(a, b, out, title):
     with open(out, "w") as f:
         f.write(f"# {title}\n\nTwo `rocprofv3 --pmc ... --kernel-trace` passes of eight SQ counters each over one product "
                 "(`bench.py --steps 1 --warmup 0`), summed per kernel.  Shares of the waves' lifetime (SQ_WAVE_CYCLES): parked = "
-                "SQ_WAIT_ANY (s_waitcnt / barrier), issue stall = SQ_WAIT_INST_ANY, issuing = SQ_ACTIVE_INST_ANY.  Pipe busy = "
-                "SQ_ACTIVE_INST_x / SQ_BUSY_CYCLES x 4 (quad-cycles of the instruction type over the SQ's busy cycles; gfx94x-style "
-                "derivation, ROCm 7.2 ships no gfx950 formulas).  Bank conflicts = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.\n\n")
+                "SQ_WAIT_ANY (s_waitcnt / barrier), issue stall = SQ_WAIT_INST_ANY, issuing = SQ_ACTIVE_INST_ANY.  VALU busy = "
+                "SQ_ACTIVE_INST_VALU / (8 x SQ_BUSY_CYCLES): quad-cycles x 4, summed over 256 CUs x 4 SIMDs, over the kernel's busy cycles "
+                "(SQ_BUSY_CYCLES is summed over the chip's 32 SQ instances); LDS busy = SQ_LDS_IDX_ACTIVE / (8 x SQ_BUSY_CYCLES): the LDS "
+                "array's active cycles per CU over the same time.  Bank conflicts = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.  (Own "
+                "derivation: ROCm 7.2 ships no gfx950 formulas.)\n\n")
         f.write("| kernel | launches | waves parked | issue stall | issuing | VALU busy | LDS busy | LDS bank-conflict share | VALU / SALU / LDS / VMEM-rd / VMEM-wr instructions per wave-cycle x1000 |\n")
         f.write("|---|---:|---:|---:|---:|---:|---:|---:|---|\n")
         for k in names:
@@ -58,8 +60,8 @@ def main(a, b, out, title):
                 return f"{100.0 * x / d:.0f} %" if d == d and d else "-"
             lds_act = c.get("SQ_LDS_IDX_ACTIVE", 0)
             f.write(f"| `{k}` | {calls[k]} | {pct(c.get('SQ_WAIT_ANY', 0), wc)} | {pct(c.get('SQ_WAIT_INST_ANY', 0), wc)} | "
-                    f"{pct(c.get('SQ_ACTIVE_INST_ANY', 0), wc)} | {pct(4 * c.get('SQ_ACTIVE_INST_VALU', 0), busy)} | "
-                    f"{pct(4 * c.get('SQ_ACTIVE_INST_LDS', 0), busy)} | {pct(c.get('SQ_LDS_BANK_CONFLICT', 0), lds_act) if lds_act else '-'} | "
+                    f"{pct(c.get('SQ_ACTIVE_INST_ANY', 0), wc)} | {pct(c.get('SQ_ACTIVE_INST_VALU', 0), 8 * busy)} | "
+                    f"{pct(c.get('SQ_LDS_IDX_ACTIVE', 0), 8 * busy)} | {pct(c.get('SQ_LDS_BANK_CONFLICT', 0), lds_act) if lds_act else '-'} | "
                     + " / ".join(f"{1000.0 * c.get(n, 0) / wc:.1f}" if wc == wc else "-" for n in
                                  ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")) + " |\n")
         f.write("\nRaw sums:\n\n| kernel | " + " | ".join(sorted({n for k in names for n in acc[k]})) + " |\n")
