@@ -911,36 +911,65 @@ __global__ __launch_bounds__(kHubThreads) void hub_plan_kernel(
     __builtin_amdgcn_wave_barrier();
     uint64_t done = 0;   // runs of the job's earlier chunk batches
     const uint64_t cell0 = CELLS ? jobcell[blockIdx.x] : 0ull;
+    // The walk is a chain of dependent loads per batch of 64 chunks (chunk table -> run table -> first entries -> columns), and
+    // a job of one-entry chunks has hundreds of batches: the chunk-table loads of batch t + 2 and the run-table loads of batch
+    // t + 1 are in flight while batch t's runs are walked, four groups of 64 runs at a time.
+    constexpr int XU = 4;
+    auto load1 = [&](uint32_t t0, uint32_t &bs, uint32_t &nb) {   // chunk table: B row and length of chunk t0 + lane
+        const uint32_t t = t0 + lane;
+        bs = 0; nb = 0;
+        if (t0 < tb && t < tb) { bs = ct_bs[t]; nb = (uint32_t)(ct_off[t + 1] - ct_off[t]); }
+    };
+    auto load2 = [&](uint32_t bs, uint32_t nb, uint32_t &g0, uint32_t &g1) {   // run table: the chunk's first run and the one behind its last
+        g0 = ht.sx[bs];                       // (clamped, branch-free: a chunk without entries reads two equal values... of entry bs)
+        g1 = ht.sx[(uint64_t)bs + nb];
+    };
+    uint32_t bs_a, nb_a, bs_b, nb_b, g0_a, g1_a;
+    load1(ta, bs_a, nb_a);
+    load1(ta + kWave, bs_b, nb_b);
+    load2(bs_a, nb_a, g0_a, g1_a);
     for (uint32_t t0 = ta; t0 < tb; t0 += kWave) {
         const uint32_t t = t0 + lane;
-        uint32_t bs = 0, g0 = 0, nr = 0;
-        if (t < tb) {
-            bs = ct_bs[t];
-            const uint32_t nb = (uint32_t)(ct_off[t + 1] - ct_off[t]);
-            if (nb) { g0 = ht.sx[bs]; nr = ht.sx[(uint64_t)bs + nb] - g0; }
-        }
+        const uint32_t bs = bs_a, g0 = g0_a, nr = g1_a - g0_a;   // (a chunk without entries: no runs)
+        // the next batch's run table and the chunk table of the batch after it go out now
+        uint32_t g0_n, g1_n, bs_c, nb_c;
+        load2(bs_b, nb_b, g0_n, g1_n);
+        load1(t0 + 2 * kWave, bs_c, nb_c);
         const uint32_t incl = wave_incl_scan(nr), pre = incl - nr;
         const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (CELLS && t < tb) chunk_off[perm[t]] = hub_desc(cell0 + done + pre);
-        for (uint32_t x0 = 0; x0 < T; x0 += kWave) {
-            const uint32_t x = x0 + lane;
-            uint32_t lo = 0, hi = kWave;   // last lane whose runs start at or before x (lanes without runs never win)
+        for (uint32_t x0 = 0; x0 < T; x0 += XU * kWave) {
+            uint32_t e0[XU], e1[XU], cbs[XU], blk[XU];
 #pragma unroll
-            for (int step = 0; step < 6; step++) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if ((uint32_t)__shfl((int)pre, (int)mid) <= x) lo = mid; else hi = mid;
+            for (int u = 0; u < XU; u++) {
+                const uint32_t x = x0 + u * kWave + lane;
+                uint32_t lo = 0, hi = kWave;   // last lane whose runs start at or before x (lanes without runs never win)
+#pragma unroll
+                for (int step = 0; step < 6; step++) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if ((uint32_t)__shfl((int)pre, (int)mid) <= x) lo = mid; else hi = mid;
+                }
+                const uint32_t xr = x - (uint32_t)__shfl((int)pre, (int)lo);
+                const uint32_t gl = (uint32_t)__shfl((int)g0, (int)lo);   // (every lane takes part in the shuffle: never under `x < T`)
+                const uint32_t g = x < T ? gl + xr : 0u;                  // clamped: the loads go out together
+                cbs[u] = (uint32_t)__shfl((int)bs, (int)lo);
+                e0[u] = ht.runstart[g];
+                e1[u] = ht.runstart[g + 1];
             }
-            const uint32_t xr = x - (uint32_t)__shfl((int)pre, (int)lo);
-            const uint32_t g = (uint32_t)__shfl((int)g0, (int)lo) + xr;
-            const uint32_t cbs = (uint32_t)__shfl((int)bs, (int)lo);
-            if (x < T) {
-                const uint32_t e0 = ht.runstart[g], e1 = ht.runstart[g + 1];
-                const uint32_t blk = b_colidx[e0] >> ht.sh;
-                const uint32_t old = atomicAdd(&hist[blk], e1 - e0);   // (lanes in flat run order: the order inside a block)
-                if (CELLS) cells[cell0 + done + x] = old - (e0 - cbs);
+#pragma unroll
+            for (int u = 0; u < XU; u++) blk[u] = b_colidx[e0[u]] >> ht.sh;
+#pragma unroll
+            for (int u = 0; u < XU; u++) {
+                const uint32_t x = x0 + u * kWave + lane;
+                if (x < T) {
+                    const uint32_t old = atomicAdd(&hist[blk[u]], e1[u] - e0[u]);   // (lanes and groups in flat run order: the order inside a block)
+                    if (CELLS) cells[cell0 + done + x] = old - (e0[u] - cbs[u]);
+                }
             }
         }
         done += T;
+        bs_a = bs_b; nb_a = nb_b; g0_a = g0_n; g1_a = g1_n;
+        bs_b = bs_c; nb_b = nb_c;
     }
     __builtin_amdgcn_wave_barrier();
     if (!CELLS) {
