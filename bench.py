@@ -7,16 +7,22 @@
     python bench.py --gpus N ...                             # same: spawns the N rank processes itself
 
 A "step" is one complete product with the operands already resident in HBM: symbolic chunk layout, multiply, merge
-into CSR.  For N > 1 one invocation measures BOTH decompositions, each over W warm-up and K timed steps:
-  k     the shared dimension k is cut into N slabs of equal partial-product count; a rank receives ONLY its columns of A
-        and rows of B, forms its partial CSR over all rows, one all-to-all-v over RCCL exchanges the partial CSRs by output
-        row range, and each rank merges the pieces of its range (BASELINE.json north_star / configs[3]) -- this is the
-        line's `value`;
-  rows  output rows sharded over the ranks, operands replicated, no exchange -- reported beside it under
-        "decompositions" (SURVEY.md 8e's fallback for products whose exchange dominates).
-Every run ends with an untimed whole-result check (1^T C 1 = (1^T A)(B 1)); at N = 1 the CPU reference is timed on a
+into CSR.  For N > 1 one invocation measures the decompositions, each over W warm-up and K timed steps:
+  k          the shared dimension k is cut into N slabs of equal partial-product count; a rank receives ONLY its columns of A
+             and rows of B, multiplies, one all-to-all-v over RCCL exchanges the partial products by output row range, and each
+             rank merges the pieces of its range (BASELINE.json north_star / configs[3]);
+  k_library  the same decomposition inside the library (osp_spgemm_multi: one process drives the N GPUs, copies on one stream
+             per destination behind the multiply, merge overlapped with the exchange), in a child process of rank 0 -- the
+             line's `value` when it ran and its whole-result check passed, else `k`;
+  rows       output rows sharded over the ranks, operands replicated, no exchange (SURVEY.md 8e's fallback for products whose
+             exchange dominates).
+All of them stay under "decompositions"; "fabric" says which backend, world size and devices the ranks saw.
+Every run ends with an untimed whole-result check (1^T C 1 = (1^T A)(B 1)).  At N = 1: the CPU reference is timed on a
 k-slab of the same matrix and the GPU's result for that slab is compared with it (indices exact, values <= 1e-6
-relative).  Rank 0 prints ONE JSON line.
+relative); a plain copy is timed on the library's stream first (roofline.peak_measured: both fractions, of the data
+sheet's 8 TB/s and of that copy); the default run adds five secondary workloads (extra_workloads), two of them --
+the web-Google shape and the uniform R-MAT-22 -- with the CPU reference run IN FULL beside them and the whole GPU
+result compared with it.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -551,6 +557,14 @@ def kernel_roofline(infos, n, E):
         nbytes = 2.0 * 4 * minfo["direct_partials"] / npl
         kernels["direct_plan_kernel"] = {"algorithmic_bytes_per_launch": nbytes, "ms_per_launch": per, "launches_per_step": npl,
                                          "GBps": (nbytes / (per * 1e-3) / 1e9) if per > 0 else 0.0}
+    if minfo.get("hub_plan_launches"):
+        # the plan of the hub rows: two walks over the runs of their chunks (two run-table entries and one column per run), one cell written per run
+        nh = minfo["hub_plan_launches"]
+        per = mean("ms_hub_plan_kernel", minfos) / nh
+        nbytes = (2.0 * 12 + 4) * minfo["hub_cells"] / nh
+        kernels["hub_plan_kernel"] = {"algorithmic_bytes_per_launch": nbytes, "ms_per_launch": per, "launches_per_step": nh,
+                                      "GBps": (nbytes / (per * 1e-3) / 1e9) if per > 0 else 0.0,
+                                      "what": "per panel: both walks, the scans between them and one read-back"}
     for k in kernels.values():
         k["frac_of_peak"] = k["GBps"] / HBM_PEAK_GBS
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
@@ -599,6 +613,7 @@ def extra_workload(ctx, name, n, csr, csc, args, np_dtype, tdtype, device, E, st
     rec = {"ms_per_step": ms, "steps": steps, "value": info["nnz_c"] / (ms * 1e-3), "unit": "nnz/s",
            "partials_per_s": info["partials"] / (ms * 1e-3), "n": n, "nnz_a": int(info["nnz_a"]), "partials": int(info["partials"]),
            "nnz_c": int(info["nnz_c"]), "panels": int(info["panels"]), "streamed": bool(stream),
+           "long_row_partials_direct": int(info["direct_partials"]), "long_row_partials_hub": int(info["hub_partials"]),
            "whole_product_GBps_algorithmic": alg / (ms * 1e-3) / 1e9, "whole_product_frac_of_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "whole_product_frac_of_measured": (alg / (ms * 1e-3) / 1e9 / copy_gbps) if copy_gbps else None,
            "phases_ms": {k: float(np.mean([i[k] for i in infos])) for k in ("ms_symbolic", "ms_multiply", "ms_merge", "ms_compact", "ms_total")},
@@ -807,6 +822,8 @@ def main():
             "panels": info["panels"], "long_rows": info["heavy_rows"], "long_row_partials": info["heavy_partials"],
             # long rows the multiply wrote straight into their column ranges (no split pass), and the ones split afterwards
             "long_rows_direct": info["direct_rows"], "long_row_partials_direct": info["direct_partials"],
+            # rows beyond the one-workgroup planner that the multiply wrote into uniform column blocks (no stretch split)
+            "long_rows_hub": info["hub_rows"], "long_row_partials_hub": info["hub_partials"],
             "long_row_partials_split_by_one_workgroup": info["split_partials"],
             "segments_global_sorted": info["sorted_segments"], "segment_partials_global_sorted": info["sorted_partials"],
             "roofline": roof,

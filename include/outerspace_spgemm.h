@@ -118,6 +118,9 @@ typedef struct osp_result_info {
     uint64_t hub_rows;          /* since version 4: rows beyond the one-workgroup planner (> 128 K partial products) that the multiply
                                    wrote straight into uniform column blocks (no stretch split) */
     uint64_t hub_partials;      /* partial products in those rows */
+    uint64_t hub_cells;         /* (chunk, run of B's row) cells planned for them: one per run the multiply writes */
+    float ms_hub_plan_kernel;   /* the two hub_plan_kernel launches, the scans between them and the read-back, per panel with hub rows */
+    uint32_t hub_plan_launches; /* panels with hub rows */
     uint64_t output_slack_bytes;/* since version 4: bytes of the result's colidx / vals allocations beyond nnz_c entries (they are
                                    sized by the bound sum_i min(U_i, N) before the merge; copied to exact size only when the
                                    slack exceeds a tenth of the device's memory -- 0 after such a copy) */

@@ -247,7 +247,7 @@ struct Result {
 
 struct PhaseTimer {
     hipStream_t s;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[8];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[9];
     explicit PhaseTimer(hipStream_t st) : s(st) {}
     ~PhaseTimer() {
         for (auto &v : ev) for (auto &p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -278,7 +278,7 @@ struct EventPair {
     EventPair &operator=(const EventPair &) = delete;
     float ms() const { float t = 0; (void)hipEventElapsedTime(&t, a, b); return t; }
 };
-enum { PH_SYM = 0, PH_MUL = 1, PH_MERGE = 2, PH_COMPACT = 3, PH_MUL_K = 4, PH_MERGE_K = 5, PH_SPLIT_K = 6, PH_PLAN_K = 7 };
+enum { PH_SYM = 0, PH_MUL = 1, PH_MERGE = 2, PH_COMPACT = 3, PH_MUL_K = 4, PH_MERGE_K = 5, PH_SPLIT_K = 6, PH_PLAN_K = 7, PH_HUB_K = 8 };
 
 // debugging aid: OSP_SYNC=1 waits for the stream at the marked points of a product and names them on stderr, so
 // that an asynchronous GPU fault is pinned to the step that caused it (the last name printed COMPLETED)
@@ -747,7 +747,7 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
             OSP_HIP(hipStreamSynchronize(s));   // (tmp goes back to the pool; everything that read it is done)
             ds->hub.sx = sx; ds->hub.runstart = runstart; ds->hub.sh = sh;
         }
-        tm.begin(PH_PLAN_K);
+        tm.begin(PH_HUB_K);
         uint64_t *jobruns = sc.get<uint64_t>(pl.nblocks + 1);
         uint64_t *jobscan_tmp = sc.get<uint64_t>(scan_scratch_entries(pl.nblocks + 1));
         const size_t hub_lds = sizeof(uint32_t) << hub_b;
@@ -762,9 +762,11 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
         hub_plan_kernel<true><<<(unsigned)pl.nblocks, kHubThreads, hub_lds, s>>>(pl.p0.long_rows, nlong, pl.blkbase, pl.hbase, pl.hbits, pl.nstretch, row_off,
                                                                           ds->rowfirst, ds->off, ds->bs, ds->perm, ds->b_colidx, ds->hub, pl.ghist,
                                                                           pl.hoff, nullptr, jobruns, hcells, ds->chunk_off);
-        tm.end(PH_PLAN_K);
+        tm.end(PH_HUB_K);
         pl.hub.cells = hcells;
         pl.hub.sx = ds->hub.sx;
+        res->info.hub_plan_launches++;
+        res->info.hub_cells += ncells;
         res->info.hub_rows += pl.mode_rows[kModeStretch];
         res->info.hub_partials += pl.mode_partials[kModeStretch];
         dbg_sync(s, "plan of the hub rows");
@@ -1536,6 +1538,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     res->info.ms_merge_kernel = tm.total(PH_MERGE_K);
     res->info.ms_split_kernel = tm.total(PH_SPLIT_K);
     res->info.ms_direct_plan_kernel = tm.total(PH_PLAN_K);
+    res->info.ms_hub_plan_kernel = tm.total(PH_HUB_K);
 }
 
 // COO (device arrays, any order) -> compressed by `seg` with ascending `inner` indices; all outputs in `sc`.
