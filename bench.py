@@ -863,7 +863,9 @@ def main():
         if t:
             roof["traffic"], roof["traffic_source"], roof["traffic_library_id"] = t
             # a recorded figure, not a property of this run: stale when the kernels have changed since the PMC passes
-            roof["traffic_stale"] = (roof["traffic_library_id"] or {}).get("kernel_source_sha16") != out["library_id"]["kernel_source_sha16"]
+            # (the same binary, or a build of the same sources: either hash matching means the counters belong to these kernels)
+            rec_id, cur_id = roof["traffic_library_id"] or {}, out["library_id"]
+            roof["traffic_stale"] = not any(rec_id.get(k) is not None and rec_id.get(k) == cur_id.get(k) for k in ("kernel_source_sha16", "so_sha16"))
         default_workload = (args.workload == "rmat" and args.rmat == "mild" and args.scale == 22 and not args.stream_output
                             and args.partial_capacity == 0 and a_mtx is None)
         if args.extras and default_workload and status == 0:
