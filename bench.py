@@ -823,7 +823,7 @@ def main():
             # long rows the multiply wrote straight into their column ranges (no split pass), and the ones split afterwards
             "long_rows_direct": info["direct_rows"], "long_row_partials_direct": info["direct_partials"],
             # rows beyond the one-workgroup planner that the multiply wrote into uniform column blocks (no stretch split)
-            "long_rows_hub": info["hub_rows"], "long_row_partials_hub": info["hub_partials"],
+            "long_rows_hub": info["hub_rows"], "long_row_partials_hub": info["hub_partials"], "hub_cells": info["hub_cells"],
             "long_row_partials_split_by_one_workgroup": info["split_partials"],
             "segments_global_sorted": info["sorted_segments"], "segment_partials_global_sorted": info["sorted_partials"],
             "roofline": roof,

@@ -570,6 +570,7 @@ struct DirectSrc {
     uint64_t K = 0, nnz_b = 0;
     Scratch *keep = nullptr;
     mutable HubTables hub{};
+    mutable bool hub_refused = false;   // a panel's hub rows turned out to be runs of a few records each: the product keeps the stretch split
 };
 
 // What is decided about a panel BEFORE its partial products exist (plan_panel) and used after the multiply (merge_panel).
@@ -654,7 +655,7 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
     const double hub_min_share = getenv("OSP_HUB_MIN_SHARE") ? atof(getenv("OSP_HUB_MIN_SHARE")) : 0.2;
     bool hub_decided = false;
     for (int attempt = 0; attempt < 3; attempt++) {
-        const bool hub_possible = ds && ds->b_rowptr && ds->keep && ctx->rank_atomic && hub_env;
+        const bool hub_possible = ds && ds->b_rowptr && ds->keep && ctx->rank_atomic && hub_env && !ds->hub_refused;
         if (!hub_possible) hub_b = 0;
         split_params_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(pl.p0.long_rows, nlong, row_off, colbits, row_max, bits_cap, ds ? ds->rowfirst : nullptr,
                                                                  ds ? ds->direct_max : 0ull, kCap, pl.hbits, pl.hmode, pl.nstretch, nseg, nhist, ncellh,
@@ -758,17 +759,27 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
         device_exclusive_scan<LoadU64, uint64_t>(LoadU64{jobruns}, pl.nblocks, jobruns, jobscan_tmp, s);
         const uint64_t ncells = d2h(jobruns + pl.nblocks, s);
         if (ncells >= (1ull << 40)) throw Error(OSP_ERR_CAPACITY, "hub rows: too many runs in one panel");
-        uint32_t *hcells = sc.get<uint32_t>(ncells);
-        hub_plan_kernel<true><<<(unsigned)pl.nblocks, kHubThreads, hub_lds, s>>>(pl.p0.long_rows, nlong, pl.blkbase, pl.hbase, pl.hbits, pl.nstretch, row_off,
-                                                                          ds->rowfirst, ds->off, ds->bs, ds->perm, ds->b_colidx, ds->hub, pl.ghist,
-                                                                          pl.hoff, nullptr, jobruns, hcells, ds->chunk_off);
-        tm.end(PH_HUB_K);
-        pl.hub.cells = hcells;
-        pl.hub.sx = ds->hub.sx;
-        res->info.hub_plan_launches++;
-        res->info.hub_cells += ncells;
-        res->info.hub_rows += pl.mode_rows[kModeStretch];
-        res->info.hub_partials += pl.mode_partials[kModeStretch];
+        // Runs of a few records each are not worth writing one by one: the multiply of such a panel loses more than the stretch
+        // split costs (R-MAT-19 "mild" at edge factor 64: 4.2 records per run, 316 -> 354 ms with hub rows; Graph500 skew: 7.6-43
+        // records per run, 7-12 % faster).  Below OSP_HUB_MIN_RUN records per run on average (default 6) the panel -- and the
+        // rest of the product -- keeps the stretch split (with the blocks already chosen: its histogram has the same layout).
+        const double min_run = getenv("OSP_HUB_MIN_RUN") ? atof(getenv("OSP_HUB_MIN_RUN")) : 6.0;
+        if ((double)pl.mode_partials[kModeStretch] < min_run * (double)ncells) {
+            ds->hub_refused = true;
+            tm.end(PH_HUB_K);
+        } else {
+            uint32_t *hcells = sc.get<uint32_t>(ncells);
+            hub_plan_kernel<true><<<(unsigned)pl.nblocks, kHubThreads, hub_lds, s>>>(pl.p0.long_rows, nlong, pl.blkbase, pl.hbase, pl.hbits, pl.nstretch, row_off,
+                                                                              ds->rowfirst, ds->off, ds->bs, ds->perm, ds->b_colidx, ds->hub, pl.ghist,
+                                                                              pl.hoff, nullptr, jobruns, hcells, ds->chunk_off);
+            tm.end(PH_HUB_K);
+            pl.hub.cells = hcells;
+            pl.hub.sx = ds->hub.sx;
+            res->info.hub_plan_launches++;
+            res->info.hub_cells += ncells;
+            res->info.hub_rows += pl.mode_rows[kModeStretch];
+            res->info.hub_partials += pl.mode_partials[kModeStretch];
+        }
         dbg_sync(s, "plan of the hub rows");
     }
 }

@@ -1024,7 +1024,8 @@ def test_hub_rows_written_by_the_multiply(port, monkeypatch, _ctx_shared, hub, d
     chunks (runs of length one), empty chunks in between, several panels, a k range: all bit for bit against the oracle."""
     from outerspace_amd import spgemm as S
     monkeypatch.setenv("OSP_HUB", hub)
-    monkeypatch.setenv("OSP_HUB_MIN_SHARE", "0")   # (by default only panels whose products are mostly in such rows plan them this way)
+    monkeypatch.setenv("OSP_HUB_MIN_SHARE", "0")   # (by default only panels whose products are mostly in such rows plan them this way ...
+    monkeypatch.setenv("OSP_HUB_MIN_RUN", "0")     #  ... and only where a run holds six records on average)
     monkeypatch.setenv("OSP_SPLIT_ROW_MAX", "3000")
     monkeypatch.setenv("OSP_DIRECT_MAX", "3000")
     c = _ctx_shared
@@ -1060,6 +1061,11 @@ def test_hub_rows_written_by_the_multiply(port, monkeypatch, _ctx_shared, hub, d
     assert_same(got, want)
     if hub == "1":
         assert got.info["hub_rows"] == 1
+        # the same row with the default threshold: its runs are single records, the panel keeps the stretch split (same bits)
+        monkeypatch.setenv("OSP_HUB_MIN_RUN", "6")
+        got, want = run_both(c, port, M, K, N, a, b, dt)
+        assert_same(got, want)
+        assert got.info["hub_rows"] == 0
 
 
 @pytest.mark.parametrize("direct_max", [None, "0", "5000", "40000"])
