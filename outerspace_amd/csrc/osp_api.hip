@@ -652,6 +652,8 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
     // the instantiation that knows their descriptors (74 registers instead of 68) for ALL its products, and the plan has fixed
     // costs.  Measured (round 4): Graph500 scale 22 streamed 3.48 -> 3.23 s, scale 20 387 -> 368 ms with them (stretch rows:
     // more than half of the products); R-MAT-22 "mild" (2 %) 236 -> 250 ms.  OSP_HUB_MIN_SHARE moves the threshold.
+    // fine bins of the direct rows' planner: 2^direct_fine per kSplitTarget products (osp_split.h, split_params_kernel)
+    const int direct_fine = getenv("OSP_DIRECT_FINE") ? std::max(0, std::min(atoi(getenv("OSP_DIRECT_FINE")), 4)) : 2;
     const double hub_min_share = getenv("OSP_HUB_MIN_SHARE") ? atof(getenv("OSP_HUB_MIN_SHARE")) : 0.2;
     bool hub_decided = false;
     for (int attempt = 0; attempt < 3; attempt++) {
@@ -659,7 +661,7 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
         if (!hub_possible) hub_b = 0;
         split_params_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(pl.p0.long_rows, nlong, row_off, colbits, row_max, bits_cap, ds ? ds->rowfirst : nullptr,
                                                                  ds ? ds->direct_max : 0ull, kCap, pl.hbits, pl.hmode, pl.nstretch, nseg, nhist, ncellh,
-                                                                 hub_b);
+                                                                 hub_b, direct_fine);
         zero_async(s, {{totals, 6 * sizeof(uint64_t)}});
         mode_totals_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(pl.p0.long_rows, nlong, row_off, pl.hmode, totals);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{pl.nstretch}, nlong, pl.blkbase, pl.hscan_tmp, s);
