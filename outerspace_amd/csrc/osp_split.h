@@ -57,6 +57,10 @@ constexpr int kSplitTarget = OSP_SPLIT_TARGET;     // aim for segments of about 
 #endif
 constexpr int kSplitRowBits = OSP_SPLIT_ROW_BITS;      // rows of at most 2^9 segments (<= 128K entries) are split by ONE workgroup (8: +0.8 %, 10: slower)
 constexpr uint64_t kSplitRowMax = (uint64_t)kSplitTarget << kSplitRowBits;  // longer rows: one workgroup per stretch
+#ifndef OSP_DIRECT_FINE_BITS
+#define OSP_DIRECT_FINE_BITS 9
+#endif
+constexpr int kDirectFineBits = OSP_DIRECT_FINE_BITS;  // fine bins of direct_plan_kernel: at most 2^this per row (LDS of the planner)
 
 // How a long row reaches the tile kernel (hmode):
 //   kModeSplitRow  one workgroup moves it into 2^b column ranges of the second buffer (split_row_kernel)
@@ -108,7 +112,7 @@ __global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const
     // A direct row's fine bins only serve its planner (the ranges are groups of bins): bins of kSplitTarget products -- the split's
     // segment size -- leave a range half a bin short of a tile on average (tiles 92 % full on R-MAT-22 "mild"); 2^direct_fine
     // times as many bins (up to the planner's 512) fill the tiles better: fewer tiles, longer runs, fewer cells.
-    if (direct && !capped) b = min(b + direct_fine, min(colbits, kSplitRowBits));
+    if (direct && !capped) b = min(b + direct_fine, min(colbits, kDirectFineBits));
     hbits[h] = (uint8_t)b;
     hmode[h] = direct ? kModeDirect : big ? kModeStretch : kModeSplitRow;
     nstretch[h] = ns;
@@ -660,7 +664,7 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
     const uint32_t *__restrict__ rowfirst, const uint64_t *__restrict__ ct_off, const uint32_t *__restrict__ ct_bs,
     const uint32_t *__restrict__ perm, const uint32_t *__restrict__ b_colidx, uint64_t *__restrict__ vrow_off,
     uint32_t *__restrict__ vcol0, uint32_t *__restrict__ vcol1, uint32_t *__restrict__ cells, uint64_t *__restrict__ chunk_off) {
-    constexpr int NT = kDirectThreads, NFINE = 1 << kSplitRowBits, CBL = kDirectChunkBlock, UNR = OSP_DIRECT_UNR;
+    constexpr int NT = kDirectThreads, NFINE = 1 << kDirectFineBits, CBL = kDirectChunkBlock, UNR = OSP_DIRECT_UNR;
     constexpr int kCellsLds = OSP_DIRECT_CELLS_LDS;
     __shared__ uint32_t hist[NFINE + 1];     // bin counts, then their exclusive prefix
     __shared__ uint16_t nxt[NFINE];          // first bin of the range that follows a range starting at this bin
