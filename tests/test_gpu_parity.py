@@ -646,6 +646,18 @@ def test_lattice_shape_vs_oracle(ctx, port, tname):
     res.close()
 
 
+def test_stream_copy_probe(_ctx_shared):
+    """osp_stream_copy_probe (bench.py's roofline.peak_measured): a plain copy on the context's stream, read + written bytes per
+    second.  Anything an MI355X does is far above 1 TB/s and cannot exceed the data sheet's 8; bad arguments are refused."""
+    import ctypes as C
+    from outerspace_amd import _lib
+    g = _ctx_shared.stream_copy_gbps(256 << 20, 5)
+    assert 1000.0 < g < 8000.0, g
+    out = C.c_double()
+    assert _lib.lib().osp_stream_copy_probe(_ctx_shared._h, 16, 1, C.byref(out)) == _lib.ERR_ARG
+    assert _lib.lib().osp_stream_copy_probe(_ctx_shared._h, 1 << 20, 0, C.byref(out)) == _lib.ERR_ARG
+
+
 @pytest.mark.parametrize("min_waste", ["0", "default"])
 def test_compressing_product_keeps_or_copies_its_bound_sized_arrays(port, monkeypatch, min_waste):
     """A product that compresses leaves the tails of its bound-sized arrays unused.  The copy to exact-size arrays is made only
