@@ -519,14 +519,40 @@ def add_measured_peak(roof, copy_gbps):
     return roof
 
 
-def kernel_roofline(infos, n, E):
+def serial_steps(step, infos, n=2):
+    """In a product of several panels the plan of panel p+1 runs on the context's second stream BESIDE the multiply of panel
+    p: the two share the CUs, so neither's launch duration in the timed steps is that kernel's own.  For their
+    roofline entries the product is run `n` more times with OSP_PLAN_OVERLAP=0 (every plan in line, before its own multiply);
+    `value` and the merge kernel's entry stay those of the timed steps."""
+    if not infos or not infos[-1].get("plans_overlapped"):
+        return None
+    old = os.environ.get("OSP_PLAN_OVERLAP")
+    os.environ["OSP_PLAN_OVERLAP"] = "0"
+    try:
+        return [step() for _ in range(n)]
+    finally:
+        if old is None:
+            os.environ.pop("OSP_PLAN_OVERLAP", None)
+        else:
+            os.environ["OSP_PLAN_OVERLAP"] = old
+
+
+def kernel_roofline(infos, n, E, serial=None):
     """Per-kernel roofline: algorithmic bytes per launch / mean launch duration, from
     the HIP events the library records on its own stream around exactly those launches.  In the k-sharded product the
     multiply runs in the rank's local step and the merge in its final step (`final_info`): each kernel is priced on the
-    call it ran in."""
+    call it ran in.  `serial`: infos of steps run without the plan/multiply overlap (serial_steps): the multiply's and the
+    plans' durations come from those, the overlapped ones are kept beside them."""
+    beside = None
+    if serial:
+        beside = {"multiply_kernel": float(np.mean([i["ms_multiply_kernel"] for i in infos])) / max(1, infos[-1]["multiply_launches"]),
+                  "direct_plan_kernel": float(np.mean([i["ms_direct_plan_kernel"] for i in infos])) / max(1, infos[-1]["direct_plan_launches"]),
+                  "hub_plan_kernel": float(np.mean([i["ms_hub_plan_kernel"] for i in infos])) / max(1, infos[-1]["hub_plan_launches"])}
+        timed_infos, infos = infos, serial
     info = infos[-1]
     minfos = [i.get("final_info", i) for i in infos]   # where the merge (and the split) ran
     minfo = minfos[-1]
+    tinfos = [i.get("final_info", i) for i in (timed_infos if serial else infos)]   # the merge: always the timed steps
 
     def mean(key, src=None):
         return float(np.mean([i[key] for i in (src or infos)]))
@@ -538,7 +564,7 @@ def kernel_roofline(infos, n, E):
     mul_bytes = (E * (nnz_al + info["nnz_b"]) + 2 * 8 * (n + 1) + E * Pl) / nmul
     mer_bytes = (E * minfo["partials"] + E * minfo["nnz_c"] + 8 * (nrows + 1)) / nmer
     for name, nbytes, ms, nl in (("multiply_kernel", mul_bytes, mean("ms_multiply_kernel"), nmul),
-                                 ("merge_tiles_kernel", mer_bytes, mean("ms_merge_kernel", minfos), nmer)):
+                                 ("merge_tiles_kernel", mer_bytes, mean("ms_merge_kernel", tinfos), nmer)):
         per = ms / nl
         kernels[name] = {"algorithmic_bytes_per_launch": nbytes, "ms_per_launch": per, "launches_per_step": nl,
                          "GBps": (nbytes / (per * 1e-3) / 1e9) if per > 0 else 0.0}
@@ -567,6 +593,12 @@ def kernel_roofline(infos, n, E):
                                       "what": "per panel: both walks, the scans between them and one read-back"}
     for k in kernels.values():
         k["frac_of_peak"] = k["GBps"] / HBM_PEAK_GBS
+    if beside:
+        for name, ms in beside.items():
+            if name in kernels:
+                kernels[name]["measured"] = (f"{len(serial)} steps with OSP_PLAN_OVERLAP=0 after the timed ones: in the timed steps the plan of "
+                                             "panel p+1 runs beside the multiply of panel p and both take longer (ms_per_launch_beside)")
+                kernels[name]["ms_per_launch_beside"] = ms
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
     return {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
@@ -608,7 +640,7 @@ def extra_workload(ctx, name, n, csr, csc, args, np_dtype, tdtype, device, E, st
     info = infos[-1]
     chk = check_sum(step(checksum=True)["val_sum_global"], expected_value_sum(n, csr, csc, device), args.dtype, name)
     ms = dt / steps * 1e3
-    roof = kernel_roofline(infos, n, E)
+    roof = kernel_roofline(infos, n, E, serial_steps(step, infos, 1))
     alg = 2 * E * info["partials"] + E * (2 * info["nnz_a"] + info["nnz_c"]) + 8 * (3 * n + 3)
     rec = {"ms_per_step": ms, "steps": steps, "value": info["nnz_c"] / (ms * 1e-3), "unit": "nnz/s",
            "partials_per_s": info["partials"] / (ms * 1e-3), "n": n, "nnz_a": int(info["nnz_a"]), "partials": int(info["partials"]),
@@ -618,7 +650,8 @@ def extra_workload(ctx, name, n, csr, csc, args, np_dtype, tdtype, device, E, st
            "whole_product_frac_of_measured": (alg / (ms * 1e-3) / 1e9 / copy_gbps) if copy_gbps else None,
            "phases_ms": {k: float(np.mean([i[k] for i in infos])) for k in ("ms_symbolic", "ms_multiply", "ms_merge", "ms_compact", "ms_total")},
            "kernels": {k: {"GBps": v["GBps"], "frac_of_peak": v["frac_of_peak"], "frac_of_measured": (v["GBps"] / copy_gbps) if copy_gbps else None,
-                           "ms_per_launch": v["ms_per_launch"], "launches_per_step": v["launches_per_step"]} for k, v in roof["kernels"].items()},
+                           "ms_per_launch": v["ms_per_launch"], "launches_per_step": v["launches_per_step"],
+                           **({"ms_per_launch_beside": v["ms_per_launch_beside"]} if "ms_per_launch_beside" in v else {})} for k, v in roof["kernels"].items()},
            "result_check_rel_err": chk["rel_err"]}
     if cpu_full:
         note(f"{name}: the CPU reference on the whole product ({info['partials']} partial products)")
@@ -807,7 +840,8 @@ def main():
         note("whole-result check passed")
         nnz_c, P = info["nnz_c"], info["partials"]
         ms_step = dt / args.steps * 1e3
-        roof = add_measured_peak(kernel_roofline(infos, n, E), copy_gbps)
+        serial = serial_steps(step, infos)
+        roof = add_measured_peak(kernel_roofline(infos, n, E, serial), copy_gbps)
         alg_total = 2 * E * P + E * (2 * nnz_a + nnz_c) + 8 * (3 * n + 3)   # whole product
         out.update({
             "value": nnz_c / (ms_step * 1e-3), "ms_per_step": ms_step,
@@ -819,7 +853,9 @@ def main():
                               "frac_of_measured": alg_total / (ms_step * 1e-3) / 1e9 / copy_gbps},
             "library_id": library_id(),
             "phases_ms": {k: float(np.mean([i[k] for i in infos])) for k in ("ms_symbolic", "ms_multiply", "ms_merge", "ms_compact", "ms_total")},
-            "panels": info["panels"], "long_rows": info["heavy_rows"], "long_row_partials": info["heavy_partials"],
+            "panels": info["panels"], "plans_beside_the_previous_multiply": info["plans_overlapped"],
+            "ms_per_step_plans_in_line": float(np.mean([i["ms_total"] for i in serial])) if serial else None,
+            "long_rows": info["heavy_rows"], "long_row_partials": info["heavy_partials"],
             # long rows the multiply wrote straight into their column ranges (no split pass), and the ones split afterwards
             "long_rows_direct": info["direct_rows"], "long_row_partials_direct": info["direct_partials"],
             # rows beyond the one-workgroup planner that the multiply wrote into uniform column blocks (no stretch split)

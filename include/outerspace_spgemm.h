@@ -124,6 +124,8 @@ typedef struct osp_result_info {
     uint64_t output_slack_bytes;/* since version 4: bytes of the result's colidx / vals allocations beyond nnz_c entries (they are
                                    sized by the bound sum_i min(U_i, N) before the merge; copied to exact size only when the
                                    slack exceeds a tenth of the device's memory -- 0 after such a copy) */
+    uint64_t plans_overlapped;  /* since version 4: panels whose plan ran on the context's second stream, beside the multiply of the
+                                   panel before (products of several panels; the phase and kernel times of the two then overlap) */
 } osp_result_info_t;
 
 /* ---- context ------------------------------------------------------------------------- */

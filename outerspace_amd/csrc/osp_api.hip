@@ -14,6 +14,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,21 @@ struct Context {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // second stream of a product with several panels: the plan of panel p+1 runs on it beside the multiply of panel p
+    // (merge_pipeline); created on first use, fork/join by the two events
+    hipStream_t aux = nullptr;
+    hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+    void need_aux() {
+        if (aux) return;
+        if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess) { aux = nullptr; throw Error(OSP_ERR_HIP, "hipStreamCreate failed"); }
+        if (hipEventCreateWithFlags(&aux_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&aux_join, hipEventDisableTiming) != hipSuccess)
+            throw Error(OSP_ERR_HIP, "hipEventCreate failed");
+    }
+    void drop_aux() {
+        if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); aux = nullptr; }
+        if (aux_fork) { (void)hipEventDestroy(aux_fork); aux_fork = nullptr; }
+        if (aux_join) { (void)hipEventDestroy(aux_join); aux_join = nullptr; }
+    }
     std::multimap<size_t, void *> free_list;
     std::map<void *, size_t> live;
     size_t pooled_bytes = 0;
@@ -252,14 +268,16 @@ struct PhaseTimer {
     ~PhaseTimer() {
         for (auto &v : ev) for (auto &p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     }
-    void begin(int ph) {
+    hipStream_t on[9] = {};   // the stream the open interval of a phase was begun on (a panel's plan may run on the second stream)
+    void begin(int ph, hipStream_t st = nullptr) {
         hipEvent_t a, b;
         OSP_HIP(hipEventCreate(&a));
         OSP_HIP(hipEventCreate(&b));
-        OSP_HIP(hipEventRecord(a, s));
+        on[ph] = st ? st : s;
+        OSP_HIP(hipEventRecord(a, on[ph]));
         ev[ph].push_back({a, b});
     }
-    void end(int ph) { OSP_HIP(hipEventRecord(ev[ph].back().second, s)); }
+    void end(int ph) { OSP_HIP(hipEventRecord(ev[ph].back().second, on[ph])); }
     float total(int ph) {
         float t = 0;
         for (auto &p : ev[ph]) { float ms = 0; if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) t += ms; }
@@ -707,14 +725,13 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
                 (unsigned long long)pl.mode_rows[kModeDirect], (unsigned long long)pl.mode_partials[kModeDirect], (unsigned long long)ndcell);
     pl.ghist = sc.get<uint32_t>(pl.ncell + 1);
     pl.ghist_tmp = sc.get<uint32_t>(scan_scratch_entries(pl.ncell + 1));
-    pl.qstage = sc.get<Part<T>>(pl.nh);
     pl.vrow_off = sc.get<uint64_t>(pl.nvirt + 1);
     pl.vfirst = sc.get<uint8_t>(pl.nvirt + 1);
     pl.vcol0 = sc.get<uint32_t>(pl.nvirt + 1);
     pl.vcol1 = sc.get<uint32_t>(pl.nvirt + 1);
     if (pl.mode_rows[kModeDirect]) {
         pl.cells = sc.get<uint32_t>(ndcell);
-        tm.begin(PH_PLAN_K);
+        tm.begin(PH_PLAN_K, s);
         direct_plan_kernel<<<nlong, kDirectThreads, 0, s>>>(pl.p0.long_rows, nlong, pl.hmode, pl.hbits, nseg, pl.vbase, pl.hoff, pl.cellbase, row_off,
                                                            colbits, kCap, ds->rowfirst, ds->off, ds->bs, ds->perm, ds->b_colidx, pl.vrow_off,
                                                            pl.vcol0, pl.vcol1, pl.cells, ds->chunk_off);
@@ -754,7 +771,7 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
             OSP_HIP(hipStreamSynchronize(s));   // (tmp goes back to the pool; everything that read it is done)
             ds->hub.sx = sx; ds->hub.runstart = runstart; ds->hub.sh = sh;
         }
-        tm.begin(PH_HUB_K);
+        tm.begin(PH_HUB_K, s);
         uint64_t *jobruns = sc.get<uint64_t>(pl.nblocks + 1);
         uint64_t *jobscan_tmp = sc.get<uint64_t>(scan_scratch_entries(pl.nblocks + 1));
         const size_t hub_lds = sizeof(uint32_t) << hub_b;
@@ -1137,6 +1154,59 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         if (flag) throw Error(OSP_ERR_HIP, "the merge made no progress for seconds (a tile's predecessors never published their sizes); "
                                            "with OSP_MERGE_SHARDS > 1 that happens when fewer workgroups than shards ever run side by side");
     };
+    // With several panels the plan of panel p+1 (VALU-bound: one workgroup per long row, histograms in LDS) runs on the
+    // context's second stream beside the multiply of panel p (bound by its scattered stores, its waves mostly parked): the
+    // two share the CUs.  Fork: the second stream waits for everything queued before that multiply (so the buffers the
+    // plan takes from the pool are no longer in use by panel p-1's merge); join: the first stream waits for the plan before
+    // panel p's merge (whose scratch may be what the plan has just given back).  OSP_PLAN_OVERLAP=0 plans every panel in
+    // line, before its own multiply (debugging aid, A/B timing).
+    const bool overlap = npanels > 1 && !(getenv("OSP_PLAN_OVERLAP") && atoi(getenv("OSP_PLAN_OVERLAP")) == 0);
+    if (overlap) ctx->need_aux();
+    struct AuxScope {   // ctx->stream is the second stream while this lives
+        Context *c; hipStream_t main;
+        explicit AuxScope(Context *ctx_) : c(ctx_), main(ctx_->stream) { c->stream = c->aux; }
+        ~AuxScope() {
+            if (std::uncaught_exceptions()) (void)hipStreamSynchronize(c->aux);   // the plan's buffers go back to the pool next
+            c->stream = main;
+        }
+    };
+    typedef std::unique_ptr<PanelPlan<T>> PlanPtr;
+    auto plan_one = [&](uint32_t p, bool beside) -> PlanPtr {
+        const uint64_t r0 = bounds[p], r1 = bounds[p + 1];
+        const uint64_t base = (npanels == 1) ? off_lo : h_off[r0];
+        const uint64_t count = (npanels == 1) ? P : h_off[r1] - base;
+        PlanPtr pl(new PanelPlan<T>(ctx));
+        if (beside) {
+            AuxScope scope(ctx);
+            OSP_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_fork, 0));
+            tm.begin(PH_MERGE, ctx->stream);
+            plan_panel<T>(ctx, res, tm, *pl, d_row_off, r0, r1, base, count, colbits, ds);
+            tm.end(PH_MERGE);
+            OSP_HIP(hipEventRecord(ctx->aux_join, ctx->stream));
+            res->info.plans_overlapped++;
+        } else {
+            tm.begin(PH_MERGE);
+            plan_panel<T>(ctx, res, tm, *pl, d_row_off, r0, r1, base, count, colbits, ds);
+            tm.end(PH_MERGE);
+        }
+        return pl;
+    };
+    // the multiply of panel p, then -- beside it -- the plan of panel p+1
+    auto multiply_and_plan_next = [&](uint32_t p, PanelPlan<T> &plan, PlanPtr &nxt) {
+        const uint64_t r0 = bounds[p], r1 = bounds[p + 1];
+        const uint64_t base = (npanels == 1) ? off_lo : h_off[r0];
+        const uint64_t count = (npanels == 1) ? P : h_off[r1] - base;
+        if (plan.p0.nlong) plan.qstage = plan.sc.template get<Part<T>>(plan.nh);   // (not before: the plan may be a panel ahead)
+        const bool beside = overlap && p + 1 < npanels;
+        if (beside) OSP_HIP(hipEventRecord(ctx->aux_fork, s));
+        tm.begin(PH_MUL);
+        if (count) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm, plan.cells, plan.qstage, plan.hub.cells ? &plan.hub : nullptr);
+        tm.end(PH_MUL);
+        if (beside) {
+            nxt = plan_one(p + 1, true);
+            OSP_HIP(hipStreamWaitEvent(s, ctx->aux_join, 0));
+        }
+    };
     if (sink) {
         // ---- streaming: one output buffer sized for the largest panel's bound, reused by every panel ----
         std::vector<uint64_t> h_ub(npanels + 1);
@@ -1148,17 +1218,13 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         int64_t *prow = sc.get<int64_t>(max_rows_panel + 1);
         uint64_t *cells = sc.get<uint64_t>(2);  // [0] = 0 (entries before the panel), [1] = entries of the panel
         uint64_t nnz_total = 0;
+        PlanPtr cur, nxt;
         for (uint32_t p = 0; p < npanels; p++) {
             const uint64_t r0 = bounds[p], r1 = bounds[p + 1];
             const uint64_t base = (npanels == 1) ? off_lo : h_off[r0];
-            const uint64_t count = (npanels == 1) ? P : h_off[r1] - base;
-            PanelPlan<T> plan(ctx);
-            tm.begin(PH_MERGE);
-            plan_panel<T>(ctx, res, tm, plan, d_row_off, r0, r1, base, count, colbits, ds);
-            tm.end(PH_MERGE);
-            tm.begin(PH_MUL);
-            if (count) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm, plan.cells, plan.qstage, plan.hub.cells ? &plan.hub : nullptr);
-            tm.end(PH_MUL);
+            if (!cur) cur = plan_one(p, false);
+            PanelPlan<T> &plan = *cur;
+            multiply_and_plan_next(p, plan, nxt);
             tm.begin(PH_MERGE);
             OSP_HIP(hipMemsetAsync(cells, 0, 2 * sizeof(uint64_t), s));
             MergeIO<T> io{stage, d_row_off, r0, r1, base, prow - r0, c_col, c_val, cells, cells + 1};
@@ -1175,23 +1241,20 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
             ctx->ensure_free(2ull << 30);  // the consumer needs room of its own
             if (sink->fn(&pd, sink->user)) throw Error(OSP_ERR_ARG, "panel callback returned non-zero");
             OSP_HIP(hipStreamSynchronize(s));  // whatever the callback queued on this stream reads the buffers
+            cur = std::move(nxt);
         }
         res->info.nnz_c = nnz_total;
         return;
     }
 
+    PlanPtr cur, nxt;
     for (uint32_t p = 0; p < npanels; p++) {
         const uint64_t r0 = bounds[p], r1 = bounds[p + 1];
         const uint64_t base = (npanels == 1) ? off_lo : h_off[r0];
-        const uint64_t count = (npanels == 1) ? P : h_off[r1] - base;
-        // ---- multiply (or scatter of CSR parts) ----
-        PanelPlan<T> plan(ctx);
-        tm.begin(PH_MERGE);
-        plan_panel<T>(ctx, res, tm, plan, d_row_off, r0, r1, base, count, colbits, ds);
-        tm.end(PH_MERGE);
-        tm.begin(PH_MUL);
-        if (count) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm, plan.cells, plan.qstage, plan.hub.cells ? &plan.hub : nullptr);
-        tm.end(PH_MUL);
+        // ---- plan (unless made beside the previous panel's multiply), multiply (or scatter of CSR parts) ----
+        if (!cur) cur = plan_one(p, false);
+        PanelPlan<T> &plan = *cur;
+        multiply_and_plan_next(p, plan, nxt);
         // ---- merge ----
         tm.begin(PH_MERGE);
         MergeIO<T> io{stage, d_row_off, r0, r1, base, res->rowptr - r_lo, c_col, c_val, out_nnz + p, out_nnz + p + 1};
@@ -1199,6 +1262,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         io.abort_word = abort_word;
         merge_panel<T>(ctx, res, tm, io, colbits, plan);
         tm.end(PH_MERGE);
+        cur = std::move(nxt);
     }
     uint64_t nnz_total = 0;
     uint32_t aflag = 0;
@@ -1955,6 +2019,7 @@ int osp_context_destroy(osp_context_t c_) {
     (void)hipStreamSynchronize(c->stream);
     c->trim();
     for (auto &kv : c->live) (void)hipFree(kv.first);
+    c->drop_aux();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return OSP_OK;

@@ -1080,6 +1080,49 @@ def test_hub_rows_written_by_the_multiply(port, monkeypatch, _ctx_shared, hub, d
         assert got.info["hub_rows"] == 0
 
 
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_next_panels_plan_runs_beside_the_multiply(port, monkeypatch, _ctx_shared, overlap):
+    """A product of several panels plans panel p+1 on the context's second stream while panel p is multiplied
+    (osp_api.hip, merge_pipeline; OSP_PLAN_OVERLAP=0 plans in line).  Direct rows, hub rows and split rows in one product,
+    resident and streamed, twice in a row on one context (the pool hands the first product's buffers to the second): the
+    same bits as the oracle either way, and the info says how many plans ran beside a multiply."""
+    from outerspace_amd import spgemm as S
+    monkeypatch.setenv("OSP_PLAN_OVERLAP", overlap)
+    monkeypatch.setenv("OSP_HUB_MIN_SHARE", "0")
+    monkeypatch.setenv("OSP_HUB_MIN_RUN", "0")
+    monkeypatch.setenv("OSP_SPLIT_ROW_MAX", "3000")
+    monkeypatch.setenv("OSP_DIRECT_MAX", "2000")
+    c = _ctx_shared
+    c.algorithm = "outer"
+    for dt, preset, scale in ((np.float64, "g500", 13), (np.float32, "mild", 14)):
+        n, rows, cols, vals = gen.rmat_coo(scale, 16, preset, seed=9, dtype=dt)
+        N = n * 64
+        bcols = (cols.astype(np.uint64) * 64 + (rows.astype(np.uint64) * 13 + cols.astype(np.uint64) * 7) % 64).astype(np.uint32)
+        for rep in range(2):
+            got, want = run_both(c, port, n, n, N, (rows, cols, vals), (rows, bcols, vals), dt, partial_capacity=200000)
+            assert_same(got, want)
+            assert got.info["panels"] > 3
+            assert got.info["plans_overlapped"] == (got.info["panels"] - 1 if overlap == "1" else 0), got.info
+            got.close()
+        # streamed: the panels as they are finished
+        import torch
+        from outerspace_amd.distributed import _as_tensor
+        dev = torch.device("cuda:0")
+        acsc, bcsr = S.coo_to_csc(n, rows, cols, vals.astype(dt)), S.coo_to_csr(n, rows, bcols, vals.astype(dt))
+        t = [torch.from_numpy(a.astype(np.int32) if a.dtype == np.uint32 else a).to(dev) for a in (*acsc, *bcsr)]
+        tdt, fmt = (torch.float64, "<f8") if dt == np.float64 else (torch.float32, "<f4")
+        parts = []
+
+        def on_panel(p):
+            parts.append((_as_tensor(p["colidx"], p["nnz"], "<i4", dev, torch.int32).cpu().numpy().view(np.uint32),
+                          _as_tensor(p["vals"], p["nnz"], fmt, dev, tdt).cpu().numpy()))
+        info = c.spgemm_csc_csr_panels(dt, n, n, N, [x.data_ptr() for x in t], on_panel, partial_capacity=200000)
+        assert info["panels"] == len(parts) > 3
+        assert info["plans_overlapped"] == (info["panels"] - 1 if overlap == "1" else 0)
+        assert np.array_equal(np.concatenate([q[0] for q in parts]), want["colidx"])
+        assert np.array_equal(np.concatenate([q[1] for q in parts]), want["vals"])
+
+
 @pytest.mark.parametrize("direct_max", [None, "0", "5000", "40000"])
 def test_direct_rows_written_by_the_multiply(port, monkeypatch, _ctx_shared, direct_max):
     """Long rows that one workgroup could split are written straight into their column ranges by the multiply phase
