@@ -760,6 +760,7 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
             Scratch tmp(ctx);
             uint8_t *rowstart = tmp.get<uint8_t>(nb + 4);
             uint32_t *sx = keep.get<uint32_t>(nb + 1), *runstart = keep.get<uint32_t>(nb + 1);
+            uint16_t *runblk = keep.get<uint16_t>(nb + 2);
             uint32_t *scan_tmp = tmp.get<uint32_t>(scan_scratch_entries(nb + 1));
             OSP_HIP(hipMemsetAsync(rowstart, 0, nb + 4, s));
             hub_rowstart_kernel<<<grid_for(ds->K, 256), 256, 0, s>>>(ds->b_rowptr, ds->K, rowstart);
@@ -768,8 +769,10 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
             device_exclusive_scan<HubRunFlag, uint32_t>(flag, nb, sx, scan_tmp, s);
             compact_flagged_kernel<HubRunFlag><<<grid_for(nb, 256), 256, 0, s>>>(flag, sx, nb, 0, runstart);
             hub_runstart_end_kernel<<<1, 1, 0, s>>>(sx + nb, runstart, (uint32_t)nb);
+            OSP_HIP(hipMemsetAsync(runblk, 0, (nb + 2) * sizeof(uint16_t), s));
+            hub_runblk_kernel<<<std::min(grid_for(nb, 256), 4096u), 256, 0, s>>>(sx + nb, runstart, ds->b_colidx, sh, runblk);
             OSP_HIP(hipStreamSynchronize(s));   // (tmp goes back to the pool; everything that read it is done)
-            ds->hub.sx = sx; ds->hub.runstart = runstart; ds->hub.sh = sh;
+            ds->hub.sx = sx; ds->hub.runstart = runstart; ds->hub.runblk = runblk; ds->hub.sh = sh;
         }
         tm.begin(PH_HUB_K, s);
         uint64_t *jobruns = sc.get<uint64_t>(pl.nblocks + 1);

@@ -336,6 +336,27 @@ __device__ __forceinline__ void store_direct_part(Part<T> *p, uint32_t col, T va
     *p = Part<T>{col, val};
 #endif
 }
+// A record of a hub row: plain (OSP_NT_HUB=0) -- the runs that consecutive chunks of the row write into one block are adjacent
+// and written close in time, so partial lines meet in L2 (Graph500 scale 20: multiply 24.2 -> 23.4 ms per launch with plain
+// stores for hub AND direct rows, while the direct rows alone lose by them: R-MAT-22 mild 21.8 -> 25.1).
+#ifndef OSP_NT_HUB
+#define OSP_NT_HUB 0
+#endif
+template <class T>
+__device__ __forceinline__ void store_hub_part(Part<T> *p, uint32_t col, T val) {
+#if OSP_NT_HUB
+    stream_store_part(p, col, val);
+#else
+    *p = Part<T>{col, val};
+#endif
+}
+// one record to where chunk_dests put it (off: the chunk's offset or descriptor, wave-uniform)
+template <class T, int MODE>
+__device__ __forceinline__ void store_dest(Part<T> *p, uint64_t off, bool dir, uint32_t col, T val) {
+    if (!dir) stream_store_part(p, col, val);
+    else if (MODE == 2 && is_hub_desc(off)) store_hub_part(p, col, val);
+    else store_direct_part(p, col, val);
+}
 // (bs: where the chunk's B row starts in B's arrays; the entry is bs + l)
 template <class T, int MODE>
 __device__ __forceinline__ void store_direct(const uint32_t *__restrict__ cells, const HubArgs &hub, Part<T> *__restrict__ qstage, uint64_t desc,
@@ -344,7 +365,7 @@ __device__ __forceinline__ void store_direct(const uint32_t *__restrict__ cells,
         if (is_hub_desc(desc)) {
             const uint32_t ri = hub.sx[bs + l + 1] - 1u - hub.sx[bs];
             const uint32_t cell = hub.cells[(desc & kHubCellMask) + ri];
-            store_direct_part(&qstage[(uint32_t)(cell + l)], bc, v);
+            store_hub_part(&qstage[(uint32_t)(cell + l)], bc, v);
             return;
         }
     }
@@ -562,10 +583,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                             chunk_dests<T, QU, MODE>(cells, hub, ri[u], chunk_off, stage, qstage, off, lrel, pnl * W + lrel, bc[u], dst, dir);
 #pragma unroll
                             for (int i = 0; i < QU; i++)
-                                if (lrel >= lo[i] && lrel < hi[i]) {
-                                    if (dir[i]) store_direct_part(dst[i], bc[u], av[i] * bv[u]);
-                                    else stream_store_part(dst[i], bc[u], av[i] * bv[u]);
-                                }
+                                if (lrel >= lo[i] && lrel < hi[i]) store_dest<T, MODE>(dst[i], off[i], dir[i], bc[u], av[i] * bv[u]);
                         }
                     }
                 }
@@ -609,7 +627,7 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                         chunk_dests<T, QU, MODE>(cells, hub, ri, chunk_off, stage, qstage, off, l, l, bc, dst, dir);
 #pragma unroll
                         for (int i = 0; i < QU; i++)
-                            if (ok[i]) { if (dir[i]) store_direct_part(dst[i], bc, av[i] * bv); else stream_store_part(dst[i], bc, av[i] * bv); }
+                            if (ok[i]) store_dest<T, MODE>(dst[i], off[i], dir[i], bc, av[i] * bv);
                     }
                 }
             }

@@ -874,9 +874,17 @@ struct HubRunFlag {
     __device__ uint32_t operator()(uint64_t e) const { return (rowstart[e] || (col[e] >> sh) != (col[e - 1] >> sh)) ? 1u : 0u; }   // (rowstart[0] is set)
 };
 __global__ void hub_runstart_end_kernel(const uint32_t *nruns_p, uint32_t *runstart, uint32_t nnz) { runstart[*nruns_p] = nnz; }
+// the column block of every run (at most 2^kSplitMaxBits blocks): the planner's walks read it beside the run's bounds instead of
+// following the run's first entry into B's column indices -- a dependent, scattered 4-byte load per run
+__global__ void hub_runblk_kernel(const uint32_t *__restrict__ nruns_p, const uint32_t *__restrict__ runstart, const uint32_t *__restrict__ b_colidx,
+                                  int sh, uint16_t *__restrict__ runblk) {
+    const uint32_t nruns = *nruns_p;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nruns; g += gridDim.x * blockDim.x) runblk[g] = (uint16_t)(b_colidx[runstart[g]] >> sh);
+}
 struct HubTables {
     const uint32_t *sx = nullptr;         // runs that start before entry e: nnz(B) + 1 entries
     const uint32_t *runstart = nullptr;   // first entry of every run, and nnz(B) behind the last
+    const uint16_t *runblk = nullptr;     // column block of every run (one more entry behind the last: never used, readable)
     int sh = 0;                           // block width: 2^sh columns
 };
 // One WAVE per job of a hub row (the stretch rows' jobs: job st of a row = the chunks whose records start inside the row's
@@ -963,9 +971,8 @@ __global__ __launch_bounds__(kHubThreads) void hub_plan_kernel(
                 cbs[u] = (uint32_t)__shfl((int)bs, (int)lo);
                 e0[u] = ht.runstart[g];
                 e1[u] = ht.runstart[g + 1];
+                blk[u] = ht.runblk[g];
             }
-#pragma unroll
-            for (int u = 0; u < XU; u++) blk[u] = b_colidx[e0[u]] >> ht.sh;
 #pragma unroll
             for (int u = 0; u < XU; u++) {
                 const uint32_t x = x0 + u * kWave + lane;
