@@ -130,7 +130,9 @@ typedef struct osp_result_info {
 
 /* ---- context ------------------------------------------------------------------------- */
 int osp_context_create(int device, osp_context_t *ctx);
-/* Same, but all work is enqueued on an existing hipStream_t (e.g. torch's current stream). */
+/* Same, but all work is enqueued on an existing hipStream_t (e.g. torch's current stream).  (Products of several panels run
+   part of their planning on a second stream of the context's own, forked from and joined into this one by events inside the
+   call: to the caller the call's work is ordered on the given stream, before and after.) */
 int osp_context_create_on_stream(int device, void *hip_stream, osp_context_t *ctx);
 int osp_context_destroy(osp_context_t ctx);
 /* Return pooled device memory to the driver. */
