@@ -785,21 +785,21 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
         device_exclusive_scan<LoadU64, uint64_t>(LoadU64{jobruns}, pl.nblocks, jobruns, jobscan_tmp, s);
         const uint64_t ncells = d2h(jobruns + pl.nblocks, s);
         if (ncells >= (1ull << 40)) throw Error(OSP_ERR_CAPACITY, "hub rows: too many runs in one panel");
-        // Runs of a few records each are not worth writing one by one unless the stretch split would do no better: it scatters
-        // rounds of kSplitStretch records over the 2^b blocks -- 2 records per block and round with 2048 blocks (Graph500 scale
-        // 22: 4.7-6.9 records per run with hub rows, 13 % faster), 16 with 256 (R-MAT-19 "mild" at edge factor 64: 4.2 records per
-        // run with hub rows, 316 -> 324-354 ms).  So: hub rows where a run holds OSP_HUB_MIN_RUN records on average (default 6:
-        // Graph500 scale 16-20, 7.1-43 records per run, 6-12 % faster), or at least 4.5 and more than a round of the split would
-        // give its blocks.  Otherwise the panel -- and the rest of the product -- keeps the stretch split (with the blocks
-        // already chosen: its histogram has the same layout).
+        // Runs of a few records each are not worth writing one by one: hub rows where a run holds OSP_HUB_MIN_RUN records on
+        // average (default 4).  Measured with the run-block table and plain stores for hub records (round 4, one box, hub rows
+        // on / off): R-MAT-19 "mild" at edge factor 64, 4.2 records per run, 293 / 326 ms; Graph500 scale 22, 4.7-6.9 records per
+        // run, 13 % faster; scale 16-20, 7.1-43 records per run, 6-18 % faster; 2.4 and 1.4 records per run (R-MAT-20 / 22 "mild",
+        // a tenth and a twentieth of the products in such rows): no difference either way.  (Until the run-block table the 4.2 case
+        // lost -- 324-354 against 315 ms -- and the threshold was six, or 4.5 where the stretch split's rounds were shorter still.)
+        // Otherwise the panel -- and the rest of the product -- keeps the stretch split (with the blocks already chosen: its
+        // histogram has the same layout).
         if (getenv("OSP_VERBOSE"))
             fprintf(stderr, "[osp]   hub rows: %llu rows, %llu products in %llu runs (%.2f records per run), %llu jobs, 2^%d blocks\n",
                     (unsigned long long)pl.mode_rows[kModeStretch], (unsigned long long)pl.mode_partials[kModeStretch], (unsigned long long)ncells,
                     ncells ? (double)pl.mode_partials[kModeStretch] / (double)ncells : 0.0, (unsigned long long)pl.nblocks, hub_b);
-        const double min_run = getenv("OSP_HUB_MIN_RUN") ? atof(getenv("OSP_HUB_MIN_RUN")) : 6.0;
+        const double min_run = getenv("OSP_HUB_MIN_RUN") ? atof(getenv("OSP_HUB_MIN_RUN")) : 4.0;
         const double run = ncells ? (double)pl.mode_partials[kModeStretch] / (double)ncells : 0.0;
-        const double split_run = (double)kSplitStretch / (double)(1u << hub_b);
-        const bool accept = run >= min_run || (run >= std::min(4.5, min_run) && run >= split_run);
+        const bool accept = run >= min_run;
         if (!accept) {
             ds->hub_refused = true;
             tm.end(PH_HUB_K);

@@ -1037,7 +1037,7 @@ def test_hub_rows_written_by_the_multiply(port, monkeypatch, _ctx_shared, hub, d
     from outerspace_amd import spgemm as S
     monkeypatch.setenv("OSP_HUB", hub)
     monkeypatch.setenv("OSP_HUB_MIN_SHARE", "0")   # (by default only panels whose products are mostly in such rows plan them this way ...
-    monkeypatch.setenv("OSP_HUB_MIN_RUN", "0")     #  ... and only where a run holds six records on average)
+    monkeypatch.setenv("OSP_HUB_MIN_RUN", "0")     #  ... and only where a run holds four records on average)
     monkeypatch.setenv("OSP_SPLIT_ROW_MAX", "3000")
     monkeypatch.setenv("OSP_DIRECT_MAX", "3000")
     c = _ctx_shared
@@ -1074,7 +1074,7 @@ def test_hub_rows_written_by_the_multiply(port, monkeypatch, _ctx_shared, hub, d
     if hub == "1":
         assert got.info["hub_rows"] == 1
         # the same row with the default threshold: its runs are single records, the panel keeps the stretch split (same bits)
-        monkeypatch.setenv("OSP_HUB_MIN_RUN", "6")
+        monkeypatch.setenv("OSP_HUB_MIN_RUN", "4")
         got, want = run_both(c, port, M, K, N, a, b, dt)
         assert_same(got, want)
         assert got.info["hub_rows"] == 0
