@@ -1123,6 +1123,39 @@ def test_next_panels_plan_runs_beside_the_multiply(port, monkeypatch, _ctx_share
         assert np.array_equal(np.concatenate([q[1] for q in parts]), want["vals"])
 
 
+def test_context_on_the_callers_stream(port, monkeypatch):
+    """osp_context_create_on_stream: the product's work is ordered on the caller's stream -- operands written by kernels
+    queued on that stream just before the call, the result read by a kernel queued on it right after, no synchronisation in
+    between -- although a product of several panels plans on a second stream of the context's own (forked from and joined
+    into the caller's by events)."""
+    import torch
+    from outerspace_amd import spgemm as S
+    from outerspace_amd.distributed import _as_tensor
+    monkeypatch.setenv("OSP_DIRECT_MIN_NNZ", "0")
+    monkeypatch.setenv("OSP_DIRECT_MAX", "3000")
+    dev = torch.device("cuda:0")
+    st = torch.cuda.Stream(device=dev)
+    c = S.Context(0, stream=st.cuda_stream)
+    try:
+        n, rows, cols, vals = gen.rmat_coo(14, 16, "mild", seed=6)
+        acsc, bcsr = S.coo_to_csc(n, rows, cols, vals), S.coo_to_csr(n, rows, cols, vals)
+        want = port.spgemm(n, n, n, acsc[0], acsc[1], acsc[2] * 2.0, bcsr[0], bcsr[1], bcsr[2] * 0.5)
+        host = [torch.from_numpy(a.astype(np.int32) if a.dtype == np.uint32 else a).pin_memory() for a in (*acsc, *bcsr)]
+        with torch.cuda.stream(st):
+            t = [h.to(dev, non_blocking=True) for h in host]
+            t[2] = t[2] * 2.0      # A's and B's values are final only when these kernels, queued on the stream, have run
+            t[5] = t[5] * 0.5
+            res = c.spgemm_csc_csr_device(np.float64, n, n, n, [x.data_ptr() for x in t], partial_capacity=want["partials"] // 5 + 1)
+            _, _, va = res.device_ptrs()
+            total = _as_tensor(va, res.nnz, "<f8", dev, torch.float64).sum()
+        assert res.info["panels"] > 3 and res.info["plans_overlapped"] == res.info["panels"] - 1 and res.info["direct_rows"] > 0
+        assert float(total) == pytest.approx(float(np.sum(want["vals"])), rel=1e-12)
+        assert_same(res, want)
+        res.close()
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("direct_max", [None, "0", "5000", "40000"])
 def test_direct_rows_written_by_the_multiply(port, monkeypatch, _ctx_shared, direct_max):
     """Long rows that one workgroup could split are written straight into their column ranges by the multiply phase
