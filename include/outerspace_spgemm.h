@@ -126,6 +126,10 @@ typedef struct osp_result_info {
                                    slack exceeds a tenth of the device's memory -- 0 after such a copy) */
     uint64_t plans_overlapped;  /* since version 4: panels whose plan ran on the context's second stream, beside the multiply of the
                                    panel before (products of several panels; the phase and kernel times of the two then overlap) */
+    uint64_t gathered_rows;     /* since version 5: direct rows that were never written: the merge kernel formed their partial
+                                   products itself, tile by tile, from the plan's run descriptors (cscMulcsr inside the merge) */
+    uint64_t gathered_partials; /* partial products in those rows */
+    uint64_t gathered_runs;     /* run descriptors planned for them: one per non-empty (chunk, column range) cell */
 } osp_result_info_t;
 
 /* ---- context ------------------------------------------------------------------------- */

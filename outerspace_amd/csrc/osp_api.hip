@@ -589,6 +589,11 @@ struct DirectSrc {
     Scratch *keep = nullptr;
     mutable HubTables hub{};
     mutable bool hub_refused = false;   // a panel's hub rows turned out to be runs of a few records each: the product keeps the stretch split
+    // gathered rows (osp_kernels.h): direct rows without an over-long range are not written by the multiply at all; the tile
+    // kernel forms their records from run descriptors.  a_vals: indexed by `perm`; gstat: rows / partial products / runs (device)
+    bool gather = false;
+    const void *a_vals = nullptr, *b_vals = nullptr;
+    unsigned long long *gstat = nullptr;
 };
 
 // What is decided about a panel BEFORE its partial products exist (plan_panel) and used after the multiply (merge_panel).
@@ -609,6 +614,8 @@ template <class T> struct PanelPlan {
     uint32_t *vcol0 = nullptr, *vcol1 = nullptr;
     uint32_t *cells = nullptr;        // direct rows: range tables and (chunk, range) cells
     HubArgs hub{};                    // hub rows: (chunk, run) cells and B's run table; cells == nullptr: the panel has none
+    GatherArgs<T> ga{};               // gathered rows: the run table (runs == nullptr: the panel has none) ...
+    uint32_t *vrun_off = nullptr, *vrun_end = nullptr;   // ... and every segment's descriptors in it
     explicit PanelPlan(Context *c) : sc(c) {}
 };
 
@@ -651,6 +658,9 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
     pl.nstretch = sc.get<uint32_t>(nlong);
     uint32_t *nseg = sc.get<uint32_t>(nlong);
     uint64_t *nhist = sc.get<uint64_t>(nlong), *ncellh = sc.get<uint64_t>(nlong);
+    const bool want_gather = ds && ds->gather;
+    uint64_t *nrund = want_gather ? sc.get<uint64_t>(nlong) : nullptr, *rdbase = want_gather ? sc.get<uint64_t>((uint64_t)nlong + 1) : nullptr;
+    uint64_t nrd = 0;
     pl.blkbase = sc.get<uint64_t>((uint64_t)nlong + 1); pl.hbase = sc.get<uint64_t>((uint64_t)nlong + 1);
     pl.vbase = sc.get<uint64_t>((uint64_t)nlong + 1); pl.cellbase = sc.get<uint64_t>((uint64_t)nlong + 1);
     unsigned long long *totals = (unsigned long long *)sc.get<uint64_t>(6);
@@ -683,19 +693,22 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
         if (!hub_possible) hub_b = 0;
         split_params_kernel<<<grid_for(nlong, 256), 256, 0, s>>>(pl.p0.long_rows, nlong, row_off, colbits, row_max, bits_cap, ds ? ds->rowfirst : nullptr,
                                                                  ds ? ds->direct_max : 0ull, kCap, pl.hbits, pl.hmode, pl.nstretch, nseg, nhist, ncellh,
-                                                                 hub_b, direct_fine);
+                                                                 hub_b, direct_fine, ds ? nrund : nullptr);
         zero_async(s, {{totals, 6 * sizeof(uint64_t)}});
         mode_totals_kernel<<<std::min(grid_for(nlong, 256), 64u), 256, 0, s>>>(pl.p0.long_rows, nlong, row_off, pl.hmode, totals);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{pl.nstretch}, nlong, pl.blkbase, pl.hscan_tmp, s);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{nseg}, nlong, pl.vbase, pl.hscan_tmp, s);
         device_exclusive_scan<LoadU64, uint64_t>(LoadU64{nhist}, nlong, pl.hbase, pl.hscan_tmp, s);
         if (ds) device_exclusive_scan<LoadU64, uint64_t>(LoadU64{ncellh}, nlong, pl.cellbase, pl.hscan_tmp, s);
+        if (ds && nrund) device_exclusive_scan<LoadU64, uint64_t>(LoadU64{nrund}, nlong, rdbase, pl.hscan_tmp, s);
         ndcell = 0;
+        nrd = 0;
         {
             Gather g(s);
             g.add(&pl.nh, (const uint64_t *)pl.hoff + nlong); g.add(&pl.nblocks, (const uint64_t *)pl.blkbase + nlong);
             g.add(&pl.nvirt, (const uint64_t *)pl.vbase + nlong); g.add(&pl.ncell, (const uint64_t *)pl.hbase + nlong);
             if (ds) g.add(&ndcell, (const uint64_t *)pl.cellbase + nlong);
+            if (ds && nrund) g.add(&nrd, (const uint64_t *)rdbase + nlong);
             for (int i = 0; i < 6; i++) g.add(&tot[i], (const uint64_t *)totals + i);
             g.wait();
         }
@@ -731,11 +744,25 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
     pl.vcol1 = sc.get<uint32_t>(pl.nvirt + 1);
     if (pl.mode_rows[kModeDirect]) {
         pl.cells = sc.get<uint32_t>(ndcell);
+        GatherPlan gp{};
+        RunDesc<T> *runs = nullptr;
+        // (the run table is addressed with 32 bits; a panel whose bound does not fit writes its direct rows as before)
+        if (ds->gather && nrund && nrd < 0xffffffffull) {
+            runs = sc.get<RunDesc<T>>(std::max<uint64_t>(nrd, 1));
+            pl.vrun_off = sc.get<uint32_t>(pl.nvirt + 1);
+            pl.vrun_end = sc.get<uint32_t>(pl.nvirt + 1);
+            OSP_HIP(hipMemsetAsync(pl.vrun_off, 0xff, (pl.nvirt + 1) * sizeof(uint32_t), s));   // kNoRuns: segments of rows that are not gathered
+            gp.rdbase = rdbase; gp.vrun_off = pl.vrun_off; gp.vrun_end = pl.vrun_end;
+            gp.rowruns = sc.get<uint32_t>(nlong);
+            OSP_HIP(hipMemsetAsync(gp.rowruns, 0xff, (uint64_t)nlong * sizeof(uint32_t), s));
+            pl.ga.runs = runs; pl.ga.b_colidx = ds->b_colidx; pl.ga.b_vals = (const T *)ds->b_vals;
+        }
         tm.begin(PH_PLAN_K, s);
-        direct_plan_kernel<<<nlong, kDirectThreads, 0, s>>>(pl.p0.long_rows, nlong, pl.hmode, pl.hbits, nseg, pl.vbase, pl.hoff, pl.cellbase, row_off,
-                                                           colbits, kCap, ds->rowfirst, ds->off, ds->bs, ds->perm, ds->b_colidx, pl.vrow_off,
-                                                           pl.vcol0, pl.vcol1, pl.cells, ds->chunk_off);
+        direct_plan_kernel<T><<<nlong, kDirectThreads, 0, s>>>(pl.p0.long_rows, nlong, pl.hmode, pl.hbits, nseg, pl.vbase, pl.hoff, pl.cellbase, row_off,
+                                                              colbits, kCap, ds->rowfirst, ds->off, ds->bs, ds->perm, ds->b_colidx, pl.vrow_off,
+                                                              pl.vcol0, pl.vcol1, pl.cells, ds->chunk_off, gp, (const T *)ds->a_vals, runs);
         tm.end(PH_PLAN_K);
+        if (gp.rowruns && ds->gstat) gather_stats_kernel<<<std::min(grid_for(nlong, 256), 64u), 256, 0, s>>>(pl.p0.long_rows, nlong, row_off, gp.rowruns, ds->gstat);
 #ifdef OSP_PLAN_PROF
         if (getenv("OSP_VERBOSE")) {
             unsigned long long hp[8] = {0}, z[8] = {0};
@@ -979,7 +1006,8 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         tile_desc_kernel<(int)kCap><<<grid_for(p0.ntiles, 256), 256, 0, s>>>(p0.tile_rows, p0.ntiles, r1, io.row_off, base, 0u, j0, extra,
                                                                            nlong, tb, pl.vcol0, pl.vcol1, desc);
         tile_desc_kernel<(int)kCap><<<grid_for(p1.ntiles, 256), 256, 0, s>>>(p1.tile_rows, p1.ntiles, nvirt, vrow_off, 0, 1u, j0, extra,
-                                                                           nlong, tb, pl.vcol0, pl.vcol1, desc);
+                                                                           nlong, tb, pl.vcol0, pl.vcol1, desc, pl.ga.runs ? pl.vrun_off : nullptr,
+                                                                           pl.vrun_end);
         dbg_sync(s, "tile chain");
     } else {
         desc = sc.get<TileDesc>(ntot);
@@ -1001,6 +1029,11 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         OSP_WITH_RA(ctx, merge_tiles_kernel<T, kMergeThreads, 64, TileCap<T>::value, kMergeMaxWgs, RA>
                     <<<std::min<uint32_t>(ntot, rw_grid), kMergeThreads, 0, s>>>(desc, ntot, lv, colbits, tile_status, ticket, io.out_in, io.c_col,
                                                                                  io.c_val, io.out_out, io.ct, nshards, io.abort_word));
+    } else if (pl.ga.runs) {   // the panel has gathered rows: the instantiation that forms their records
+        const uint32_t merge_grid = ctx->cus * (uint32_t)merge_wgs_per_cu<T, kMergeThreads, TileCap<T>::value>();
+        OSP_WITH_RA(ctx, merge_tiles_kernel<T, kMergeThreads, 0, TileCap<T>::value, kMergeMaxWgs, RA, true>
+                    <<<std::min<uint32_t>(ntot, merge_grid), kMergeThreads, 0, s>>>(desc, ntot, lv, colbits, tile_status, ticket, io.out_in, io.c_col,
+                                                                                    io.c_val, io.out_out, ChunkTable<T>{}, nshards, io.abort_word, pl.ga));
     } else {
         const uint32_t merge_grid = ctx->cus * (uint32_t)merge_wgs_per_cu<T, kMergeThreads, TileCap<T>::value>();
         OSP_WITH_RA(ctx, merge_tiles_kernel<T, kMergeThreads, 0, TileCap<T>::value, kMergeMaxWgs, RA>
@@ -1569,6 +1602,14 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         if (direct) {
             dsrc = DirectSrc{rowfirst, offs_sorted, bs_sorted, perm, b_colidx, chunk_off, direct_max};
             dsrc.b_rowptr = b_rowptr; dsrc.K = K; dsrc.nnz_b = (uint64_t)nnz_b; dsrc.keep = &sc;
+            // gathered rows (osp_kernels.h): on unless OSP_GATHER=0 (debugging aid, A/B timing: every direct row is then written
+            // by the multiply, as until round 4) or the row-wise variant runs (its tile kernel is another instantiation)
+            dsrc.gather = !rowwise && !(getenv("OSP_GATHER") && atoi(getenv("OSP_GATHER")) == 0);
+            dsrc.a_vals = a_vals + e0; dsrc.b_vals = b_vals;
+            if (dsrc.gather) {
+                dsrc.gstat = (unsigned long long *)sc.get<uint64_t>(3);
+                zero_async(s, {{dsrc.gstat, 3 * sizeof(uint64_t)}});
+            }
         }
         if (rowwise) {
             ct = ChunkTable<T>{offs_sorted, bs_sorted, perm, rowfirst, a_vals + e0, b_colidx, b_vals, (uint32_t)rw_cap, 1u};
@@ -1621,6 +1662,11 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     OSP_HIP(hipEventRecord(ev.b, s));
     OSP_HIP(hipStreamSynchronize(s));
     const float ms = ev.ms();
+    if (dsrc.gstat && res->info.direct_rows) {
+        uint64_t gs[3] = {0, 0, 0};
+        copy_d2h(gs, dsrc.gstat, sizeof(gs), s);
+        res->info.gathered_rows = gs[0]; res->info.gathered_partials = gs[1]; res->info.gathered_runs = gs[2];
+    }
     if (getenv("OSP_VERBOSE")) {
         fprintf(stderr, "[osp] product done in %.1f ms; pool misses so far: %llu hipMalloc calls, %.1f GB, %.1f ms\n", ms,
                 (unsigned long long)ctx->malloc_calls, ctx->malloc_bytes / 1e9, ctx->malloc_ms);

@@ -948,6 +948,30 @@ struct TileDesc {
     // itself orders them; key = col - cbase needs kbits bits (about log2(N * tile / row length), often <= 20:
     // two sort passes).  kbits = 0: level-0 key (local row, col).
     uint32_t cbase, kbits;
+    // a tile of a GATHERED row (below): its runs are descriptors [rbeg, rbeg + rcnt) of the panel's run table, nothing of
+    // it was staged; rcnt = 0: the tile's records are in the staging buffer of its level
+    uint32_t rbeg, rcnt;
+};
+// ---- gathered rows (round 5) ---------------------------------------------------------------------------------------------
+// A direct row's plan (direct_plan_kernel, osp_split.h) knows, for every chunk (non-zero A[i,k]) and column range of the row,
+// which entries of B's row k fall into the range: a RUN of consecutive entries, because B's rows are sorted.  Until round 4 the
+// multiply wrote every run to its place in the second buffer and the tile kernel read it back: 2 x 12 bytes of HBM traffic per
+// partial product, the writes in runs of 8-75 records at unaligned addresses (the multiply's bound).  A GATHERED row is never
+// written: the planner leaves one descriptor per non-empty run -- where the run would have started in the second buffer
+// (dst: that buffer stays virtual), where it starts in B's arrays (src) and the chunk's value of A -- in the order
+// (row, range, chunk), and the tile of a range forms its products itself: a record at virtual position p of the tile belongs
+// to the last run with dst <= p, it is entry src + (p - dst) of B times av.  Same records in the same order as the written
+// tile, so the sort and the sums are bit-identical; the multiply skips the row's chunks (kChunkSkip).
+// cscMulcsr (SimSpGEMM.cpp:265-281) for these rows therefore happens inside merge_tiles_kernel.
+constexpr uint32_t kNoRuns = 0xffffffffu;   // vrun_off of a segment whose records are in the second buffer
+template <class T> struct RunDesc;
+template <> struct alignas(16) RunDesc<double> { uint32_t dst, src; double av; };
+template <> struct alignas(4) RunDesc<float> { uint32_t dst, src; float av; };
+template <class T>
+struct GatherArgs {
+    const RunDesc<T> *runs = nullptr;     // the panel's run table (null: no gathered rows)
+    const uint32_t *b_colidx = nullptr;
+    const T *b_vals = nullptr;
 };
 // Everything merge_tiles_kernel needs per level.
 template <class T>
@@ -963,7 +987,8 @@ struct MergeLevels {
 template <int CAP>
 __global__ void tile_desc_kernel(const uint32_t *tile_rows, uint32_t ntiles, uint64_t r_end, const uint64_t *row_off,
                                  uint64_t base, uint32_t lvl, const uint32_t *j0, const uint32_t *extra, uint32_t nlong,
-                                 const uint32_t *tb, const uint32_t *vcol0, const uint32_t *vcol1, TileDesc *desc) {
+                                 const uint32_t *tb, const uint32_t *vcol0, const uint32_t *vcol1, TileDesc *desc,
+                                 const uint32_t *vrun_off = nullptr, const uint32_t *vrun_end = nullptr) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
     const uint64_t ra = tile_rows[t], rb = (t + 1 < ntiles) ? (uint64_t)tile_rows[t + 1] : r_end;
@@ -975,6 +1000,8 @@ __global__ void tile_desc_kernel(const uint32_t *tile_rows, uint32_t ntiles, uin
     d.lvl = lvl;
     d.cbase = 0;
     d.kbits = 0;
+    d.rbeg = 0;
+    d.rcnt = 0;
     uint32_t pos = t;
     if (nlong) {
         if (lvl == 0) {
@@ -990,6 +1017,11 @@ __global__ void tile_desc_kernel(const uint32_t *tile_rows, uint32_t ntiles, uin
             int kb = 1;
             while (kb < 32 && (1ull << kb) < range) kb++;
             d.kbits = (uint32_t)kb;
+            // segments of a gathered row: their runs are consecutive in the run table (kNoRuns: the row was written or split)
+            if (vrun_off && vrun_off[ra] != kNoRuns && d.n <= (uint32_t)CAP) {
+                d.rbeg = vrun_off[ra];
+                d.rcnt = vrun_end[rb - 1] - d.rbeg;
+            }
         }
     }
     desc[pos] = d;
@@ -1076,11 +1108,14 @@ constexpr int merge_waves_per_simd() {
 }
 // RA: stable ranks from the return order of one LDS atomic (true) or from ballot matching (false); a context whose
 // self-test of that order fails runs the ballot instantiations (osp_api.hip, Context::rank_atomic).
-template <class T, int NT, int ABL = 0, int CAP = TileCap<T>::value, int MAXWG = kMergeMaxWgs, bool RA = (OSP_RANK_ATOMIC != 0)>
+// GA: the launch has tiles of gathered rows (TileDesc::rcnt != 0; `ga`: their run table and B); launches without them run the
+// instantiation that does not know them (a gathered tile keeps its values in registers through the sort: 12 more for f64)
+template <class T, int NT, int ABL = 0, int CAP = TileCap<T>::value, int MAXWG = kMergeMaxWgs, bool RA = (OSP_RANK_ATOMIC != 0), bool GA = false>
 __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>())) void merge_tiles_kernel(
     const TileDesc *__restrict__ desc, uint32_t ntiles, const MergeLevels<T> lvl, int colbits, uint64_t *tile_status,
     uint32_t *ticket, const uint64_t *__restrict__ out_base_p, uint32_t *__restrict__ c_col, T *__restrict__ c_val,
-    uint64_t *__restrict__ out_end_p, const ChunkTable<T> ct = ChunkTable<T>{}, uint32_t nshards = 1, uint32_t *abort_word = nullptr) {
+    uint64_t *__restrict__ out_end_p, const ChunkTable<T> ct = ChunkTable<T>{}, uint32_t nshards = 1, uint32_t *abort_word = nullptr,
+    const GatherArgs<T> ga = GatherArgs<T>{}) {
     __shared__ MergeSmem<T, NT, CAP> sm;
     __shared__ TileDesc s_dnext;
     __shared__ uint32_t s_tnext;
@@ -1095,7 +1130,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
     constexpr int IPT = LPT;
     constexpr int DPT = (kDigits + NT - 1) / NT;  // digits per thread in the scan step
     static_assert(kTileMaxRows + 1 <= NT, "row offsets are fetched one per thread");
-    const unsigned tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    unsigned tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     uint32_t shard = 0;   // (thread 0's copy is the one in use: it takes every ticket of the workgroup)
     if (tid == 0) {
         if (nshards > 1) shard = atomicAdd(&ticket[nshards * kTicketStride], 1u) % nshards;   // by arrival, see take_ticket
@@ -1120,6 +1155,14 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
     OSP_CRUMB(5, ntiles, d.lvl, d.nr);
     uint64_t ro = 0;
     PartWords<T> lrec[LPT];  // raw: unpacked at staging time, so the loads stay in flight together
+    // a thread's q-th entry of a tile is ix0 + q * ixs: tid + q * NT, or -- in the instantiation that knows gathered tiles --
+    // w * kSpan + q * 64 + lane: a wave owns a contiguous span of the tile (as in the sort passes), so that the records a wave
+    // gathers in one load are consecutive.  (For a staged tile the two are the same to the memory system: 64 consecutive
+    // records per wave and load either way.)
+    constexpr uint32_t kSpan = (uint32_t)kTileCap / NW;
+    static_assert(!GA || (kTileCap % (NW * kWave) == 0 && (int)kSpan == LPT * kWave), "gathered tiles: a wave's span is LPT wave-loads");
+    uint32_t ix0 = GA ? w * kSpan + lane : tid;
+    constexpr uint32_t ixs = GA ? (uint32_t)kWave : (uint32_t)NT;
     auto request = [&](const TileDesc &dd, bool ok) {
         bool fetch = ok && dd.n <= (uint32_t)kTileCap;
         ro = 0;
@@ -1131,9 +1174,20 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
         const Part<T> *__restrict__ stage = lvl.stage[lv_i];
         if (fetch && tid <= dd.nr) ro = lvl.row_off[lv_i][dd.ra + tid];
         if (ROWWISE && dd.lvl == 0) fetch = false;  // nothing was staged for these rows
+        if constexpr (GA) {
+            if (fetch && dd.rcnt != 0) {   // (tile-uniform) a gathered tile: nothing of it is in the staging buffers; its run number
+                                           // `tid` (dst, src) waits where a staged tile's first record would (the rest, if any, is
+                                           // loaded when the tile starts)
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 ds2 = *reinterpret_cast<const u32x2 *>(&ga.runs[tid < dd.rcnt ? dd.rbeg + tid : dd.rbeg]);
+                lrec[0].w[0] = ds2.x;
+                lrec[0].w[1] = ds2.y;
+                return;
+            }
+        }
 #pragma unroll
         for (int q = 0; q < LPT; q++) {
-            const uint32_t i = tid + q * NT;
+            const uint32_t i = ix0 + q * ixs;
             // unconditional load from a clamped address (lanes past the end read the descriptor array and
             // ignore it): a branch here makes the compiler wait for every load inside its own block
             const Part<T> *src = (fetch && i < dd.n) ? &stage[dd.s + i] : reinterpret_cast<const Part<T> *>(desc);
@@ -1144,6 +1198,11 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
     __syncthreads();  // everybody holds t / d before the slots are refilled
     OSP_PROF_DECL
     while (t < ntiles) {
+        // (The compiler hoists every per-thread index expression of the tile loop -- tid * 6 + q, addresses of the thread's
+        // counters ... some thirty values -- out of the loop and, short of registers, SPILLS them: 21 of them with the gathered
+        // path compiled in, reloaded sixty times per tile.  Hiding the thread index behind an empty asm once per tile makes
+        // them the few integer instructions they are: no spills at the same 96 registers.)
+        if constexpr (GA) { asm volatile("" : "+v"(tid)); lane = tid & 63u; w = tid >> 6; ix0 = w * kSpan + lane; }
         OSP_DESC_CHECK(t, d);
         OSP_CRUMB(1, ntiles, d.lvl, d.nr);
         const uint64_t ra = d.ra, s = d.s, base = lvl.base[d.lvl];
@@ -1192,6 +1251,56 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
         uint32_t *htab = sm.htab();
         constexpr bool INPLACE = (ABL & 32) != 0;
         const bool early = nbits > 0 && keybits < 32 && !(ABL & 2) && !(ABL & 8) && !INPLACE;
+        const bool gath = GA && d.rcnt != 0;   // (tile-uniform)
+        uint32_t kq[LPT];
+        T vq[LPT];   // the values by staging position: read back after the sort -- or, in a gathered tile, formed below and kept
+        // gathered tile: the run of each of the thread's entries (16 bits each) -- through the hash count in registers, through the
+        // sort in `pad` (idle until the values arrive; f32 tiles have none and keep the registers)
+        uint32_t rq[(LPT + 1) / 2];
+        constexpr bool kRunInPad = GA && Smem::kWide;
+        if constexpr (GA) {
+            if (gath) {
+                // ---- a gathered tile: its records are formed here (cscMulcsr for these rows) ----
+                // The tile's runs -> LDS (everything behind key0 is idle until the hash count): start inside the tile and position
+                // in B minus that start.  Entry i belongs to the last run that starts at or before i; its column is fetched now, its
+                // value after the sort (the sort needs the keys only, and a thread cannot hold six values through it).
+                static_assert(sizeof(sm.pos0) + sizeof(sm.pad) + sizeof(sm.key1) + sizeof(sm.pos1) + sizeof(sm.cnt) >= (size_t)kTileCap * (4 + 2),
+                              "gathered tiles: the run table fits behind key0");
+                uint32_t *gsrc = reinterpret_cast<uint32_t *>(sm.pos0);
+                uint16_t *gst = reinterpret_cast<uint16_t *>(gsrc + kTileCap);
+                const uint32_t R = d.rcnt, tile0 = (uint32_t)(s + base);   // (the second buffer's positions are 32 bits wide, modulo)
+                for (uint32_t x = tid; x < R; x += NT) {
+                    uint32_t dst = lrec[0].w[0], src = lrec[0].w[1];
+                    if (x != tid) { const RunDesc<T> rd = ga.runs[d.rbeg + x]; dst = rd.dst; src = rd.src; }
+                    const uint32_t st = dst - tile0;
+                    gsrc[x] = src - st;
+                    gst[x] = (uint16_t)st;
+                }
+                if (tid <= nr) sm.rowo[tid] = (uint32_t)(ro - base - s);
+                __syncthreads();
+                uint32_t bpos[LPT];
+#pragma unroll
+                for (int q = 0; q < (LPT + 1) / 2; q++) rq[q] = 0;
+#pragma unroll
+                for (int q = 0; q < LPT; q++) {
+                    const uint32_t i = ix0 + q * ixs;
+                    uint32_t lo = 0, hi = R;   // last run with gst <= i (gst[0] = 0)
+                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)gst[mid] <= i) lo = mid; else hi = mid; }
+                    bpos[q] = i < n ? gsrc[lo] + i : 0u;   // clamped: the loads below go out together
+                    rq[q >> 1] |= (i < n ? lo : 0u) << (16 * (q & 1));
+                }
+                uint32_t bc[LPT];
+#pragma unroll
+                for (int q = 0; q < LPT; q++) bc[q] = ga.b_colidx[bpos[q]];
+#pragma unroll
+                for (int q = 0; q < LPT; q++) {
+                    const uint32_t i = ix0 + q * ixs;
+                    kq[q] = bc[q] - cbase;
+                    if (i < n) sm.key0[i] = kq[q];
+                }
+                __syncthreads();   // the run table has been read: the hash table may take its place
+            }
+        }
         if (early) {
             if constexpr (ABL & 256) {
                 for (uint32_t i = tid; i < HS; i += NT) htab[i] = 0xffffffffu;
@@ -1210,13 +1319,12 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
             }
             if (tid == 0) sm.hcount = 0;
         }
-        if (tid <= nr) sm.rowo[tid] = (uint32_t)(ro - base - s);
+        if (!gath && tid <= nr) sm.rowo[tid] = (uint32_t)(ro - base - s);
         __syncthreads();
         OSP_PROF_MARK(0);
         // stage the keys: (local row << colbits) | col, or col - cbase.  The payload (staging position) is implicit
         // until pass 0; the values stay in registers until the sort is over.
         uint32_t fresh = 0;
-        uint32_t kq[LPT];
         const bool rw_tile = ROWWISE && d.lvl == 0;
         if (rw_tile) {
             if constexpr (ROWWISE) {
@@ -1288,9 +1396,10 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                 }
             }
         } else {
+            if (!gath) {
 #pragma unroll
             for (int q = 0; q < LPT; q++) {
-                const uint32_t i = tid + q * NT;
+                const uint32_t i = ix0 + q * ixs;
                 kq[q] = 0;
                 if (i < n) {
                     if (relkey) {
@@ -1303,6 +1412,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                     sm.key0[i] = kq[q];
                 }
             }
+            }
             if (early) {
                 // first probes of all the thread's keys go out together; only collisions with a different key walk on
                 uint32_t hq[LPT], oq[LPT];
@@ -1310,11 +1420,11 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                 for (int q = 0; q < LPT; q++) {
                     hq[q] = (uint32_t)(((uint64_t)(kq[q] * 2654435761u) * HS) >> 32);
                     oq[q] = kq[q];
-                    if (tid + q * NT < n) oq[q] = atomicCAS(&htab[hq[q]], 0xffffffffu, kq[q]);
+                    if (ix0 + q * ixs < n) oq[q] = atomicCAS(&htab[hq[q]], 0xffffffffu, kq[q]);
                 }
 #pragma unroll
                 for (int q = 0; q < LPT; q++) {
-                    if (tid + q * NT < n) {
+                    if (ix0 + q * ixs < n) {
                         uint32_t old = oq[q], h = hq[q];
                         while (old != 0xffffffffu && old != kq[q]) {
                             h = (h + 1 == HS) ? 0u : h + 1;
@@ -1334,6 +1444,15 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
         const uint32_t wbeg = min(w * per, n), wend = min(wbeg + per, n);
         int cur = 0;
         __syncthreads();   // keys staged, hash count complete
+        if constexpr (kRunInPad) {
+            if (gath) {
+#pragma unroll
+                for (int q = 0; q < LPT; q++) {
+                    const uint32_t i = ix0 + q * ixs;
+                    if (i < n) sm.pad[i] = (uint16_t)(rq[q >> 1] >> (16 * (q & 1)));
+                }
+            }
+        }
         OSP_PROF_MARK(1);
         if (early && tid == 0) lookback_publish(tile_status, t, sm.hcount);
         OSP_PROF_MARK(2);
@@ -1477,13 +1596,36 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
         // through the sort -- that is what lets five workgroups per CU run without spilling.  The barriers inside the
         // scan below order the LDS writes before the run sums.
         OSP_CRUMB(2, npass, cur, nbits);
-        T vq[LPT];
-        if (!rw_tile) {
+        if (!rw_tile && !gath) {
             const Part<T> *__restrict__ stg = lvl.stage[d.lvl];
 #pragma unroll
             for (int q = 0; q < LPT; q++) {
-                const uint32_t i = tid + q * NT;
+                const uint32_t i = ix0 + q * ixs;
                 vq[q] = load_part_words(i < n ? &stg[s + i] : reinterpret_cast<const Part<T> *>(desc)).val();  // clamped, branch-free
+            }
+        }
+        if constexpr (GA) {
+            if (gath) {
+                // the values of a gathered tile: the entry's run (its descriptor comes from L2) -> its place in B -> A value x B value,
+                // the product cscMulcsr forms (one rounding, as in multiply_kernel)
+                const uint32_t tile0 = (uint32_t)(s + base);
+                RunDesc<T> rdq[LPT];
+#pragma unroll
+                for (int q = 0; q < LPT; q++) {
+                    const uint32_t i = ix0 + q * ixs;
+                    uint32_t r;
+                    if constexpr (kRunInPad) r = i < n ? (uint32_t)sm.pad[i] : 0u;
+                    else r = (rq[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                    rdq[q] = ga.runs[d.rbeg + r];
+                }
+                T bv[LPT];
+#pragma unroll
+                for (int q = 0; q < LPT; q++) {
+                    const uint32_t i = ix0 + q * ixs;
+                    bv[q] = ga.b_vals[i < n ? rdq[q].src - (rdq[q].dst - tile0) + i : 0u];   // clamped, branch-free
+                }
+#pragma unroll
+                for (int q = 0; q < LPT; q++) vq[q] = rdq[q].av * bv[q];
             }
         }
         if (npass == 0) __syncthreads();
@@ -1500,10 +1642,13 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                 heads += h;
             }
         }
+        if constexpr (kRunInPad) {
+            if (gath) __syncthreads();   // every thread has read its runs from `pad`: the values may take its place
+        }
         if (!rw_tile) {
 #pragma unroll
             for (int q = 0; q < LPT; q++) {
-                const uint32_t i = tid + q * NT;
+                const uint32_t i = ix0 + q * ixs;
                 if (i < n) sval[i] = vq[q];
             }
         }
@@ -1700,6 +1845,8 @@ __global__ void seg_tile_desc_kernel(const uint32_t *mid, uint32_t nmid, const u
     int kb = 1;
     while (kb < 32 && (1ull << kb) < range) kb++;
     d.kbits = (uint32_t)kb;
+    d.rbeg = 0;
+    d.rcnt = 0;
     desc[t] = d;
 }
 

@@ -87,7 +87,7 @@ constexpr uint64_t kDirectRowCells = 1ull << 19;  // (chunk, range) cells of ONE
 __global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const uint64_t *row_off, int colbits,
                                     uint64_t row_max, int bits_cap, const uint32_t *rowfirst, uint64_t direct_max, uint32_t cap,
                                     uint8_t *hbits, uint8_t *hmode, uint32_t *nstretch, uint32_t *nseg, uint64_t *nhist, uint64_t *ncell,
-                                    int hub_b = 0, int direct_fine = 0) {
+                                    int hub_b = 0, int direct_fine = 0, uint64_t *nrund = nullptr) {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= nheavy) return;
     const uint64_t U = row_off[rows[h] + 1] - row_off[rows[h]];
@@ -119,6 +119,8 @@ __global__ void split_params_kernel(const uint32_t *rows, uint32_t nheavy, const
     nseg[h] = direct ? (uint32_t)nranges : 1u << b;
     nhist[h] = (uint64_t)ns << b;
     ncell[h] = direct ? ((1ull << b) + 3) / 4 + nc * nranges : 0ull;
+    // run descriptors of a gathered row: one per non-empty (chunk, range) cell, never more than the row has products
+    if (nrund) nrund[h] = direct ? min(nc * nranges, U) : 0ull;
 }
 struct HeavyLenIf {   // partial products of long row h if it has mode `mode` (else 0): how much each path handles
     const uint32_t *rows;
@@ -657,24 +659,50 @@ __device__ unsigned long long osp_plan_prof[8];
 #define OSP_PLAN_MARK(k)
 #define OSP_PLAN_DECL
 #endif
-__global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
+// GATHERED rows (round 5; osp_kernels.h, "gathered rows"): a direct row none of whose ranges exceeds a tile is not written by
+// the multiply at all.  Step 3 then leaves, instead of cells, one RunDesc per non-empty (chunk, range) cell in the order
+// (range, chunk) -- where the run would start in the second buffer, where it starts in B, the chunk's A value -- and the
+// bounds of every segment's descriptors (vrun_off / vrun_end); the row's chunks get kChunkSkip.  The order needs the number
+// of non-empty cells of every range before the first descriptor is written: a row whose cells fit LDS at once (nearly all)
+// counts them there; a row of several blocks of chunks leaves the blocks' counts in its (otherwise unused) cell block of
+// `cells` and reads them back, so B's columns are still walked twice, not three times.
+// rowruns[h]: the row's number of runs, kNoRuns for a row that is not gathered (statistics: gather_stats_kernel).
+struct GatherPlan {
+    const uint64_t *rdbase = nullptr;   // first descriptor of every long row's block in the run table (null: no row is gathered)
+    uint32_t *vrun_off = nullptr, *vrun_end = nullptr;   // per segment (virtual row): its descriptors
+    uint32_t *rowruns = nullptr;
+};
+// gstat[0..2] += gathered rows, their partial products, their runs (few workgroups: they end in atomics on three hot words --
+// one set per ROW inside the planner made it twice as slow)
+__global__ void gather_stats_kernel(const uint32_t *rows, uint32_t nlong, const uint64_t *row_off, const uint32_t *rowruns, unsigned long long *gstat) {
+    uint64_t nr = 0, np = 0, nd = 0;
+    for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nlong; h += gridDim.x * blockDim.x) {
+        const uint32_t r = rowruns[h];
+        if (r != kNoRuns) { nr++; nd += r; np += row_off[rows[h] + 1] - row_off[rows[h]]; }
+    }
+    nr = wave_reduce_sum<uint64_t>(nr); np = wave_reduce_sum<uint64_t>(np); nd = wave_reduce_sum<uint64_t>(nd);
+    if (lane_id() == 0 && nr) { atomicAdd(&gstat[0], (unsigned long long)nr); atomicAdd(&gstat[1], (unsigned long long)np); atomicAdd(&gstat[2], (unsigned long long)nd); }
+}
+template <class V>
+__global__ __launch_bounds__(kDirectThreads, 8) void direct_plan_kernel(
     const uint32_t *__restrict__ rows, uint32_t nlong, const uint8_t *__restrict__ hmode, const uint8_t *__restrict__ hbits,
     const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ vbase, const uint64_t *__restrict__ hoff,
     const uint64_t *__restrict__ cellbase, const uint64_t *__restrict__ row_off, int colbits, uint32_t cap,
     const uint32_t *__restrict__ rowfirst, const uint64_t *__restrict__ ct_off, const uint32_t *__restrict__ ct_bs,
     const uint32_t *__restrict__ perm, const uint32_t *__restrict__ b_colidx, uint64_t *__restrict__ vrow_off,
-    uint32_t *__restrict__ vcol0, uint32_t *__restrict__ vcol1, uint32_t *__restrict__ cells, uint64_t *__restrict__ chunk_off) {
+    uint32_t *__restrict__ vcol0, uint32_t *__restrict__ vcol1, uint32_t *__restrict__ cells, uint64_t *__restrict__ chunk_off,
+    const GatherPlan gp, const V *__restrict__ a_vals, RunDesc<V> *__restrict__ runs) {
     constexpr int NT = kDirectThreads, NFINE = 1 << kDirectFineBits, CBL = kDirectChunkBlock, UNR = OSP_DIRECT_UNR;
     constexpr int kCellsLds = OSP_DIRECT_CELLS_LDS;
-    __shared__ uint32_t hist[NFINE + 1];     // bin counts, then their exclusive prefix
-    __shared__ uint16_t nxt[NFINE];          // first bin of the range that follows a range starting at this bin
+    __shared__ alignas(8) uint32_t hist[NFINE + 1];     // bin counts, then their exclusive prefix (gathered rows, step 3: the block's A values)
+    __shared__ alignas(4) uint16_t nxt[NFINE];          // first bin of the range that follows a range starting at this bin (gathered rows, step 3: runs per range)
     __shared__ uint8_t lut[NFINE];
     __shared__ uint32_t rbin0[kDirectMaxRanges + 2], roff[kDirectMaxRanges + 2], cursor[kDirectMaxRanges + 1];
     __shared__ uint32_t cbs[CBL], cst[CBL + 1];   // per chunk of the block: (B position - first entry number), first entry number
     __shared__ uint32_t cellm[kCellsLds], lsm[kCellsLds];
     __shared__ uint32_t psum[NT];
     __shared__ uint32_t scratch[NT / kWave + 1];
-    __shared__ uint32_t s_T;
+    __shared__ uint32_t s_T, s_over;
     const uint32_t h = blockIdx.x;
     if (h >= nlong || hmode[h] != kModeDirect) return;
     OSP_PLAN_DECL
@@ -776,13 +804,15 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
     }
     __syncthreads();
     if (tid == 0) {
-        uint32_t t = 0;
-        for (uint32_t d = 0; d < nfine; d = nxt[d]) { rbin0[t] = d; roff[t] = hist[d]; t++; }
+        uint32_t t = 0, over = 0;
+        for (uint32_t d = 0; d < nfine; d = nxt[d]) { rbin0[t] = d; roff[t] = hist[d]; over |= (hist[nxt[d]] - hist[d]) > cap ? 1u : 0u; t++; }
         rbin0[t] = nfine; roff[t] = hist[nfine];
         s_T = t;
+        s_over = over;   // a range that exceeds a tile (one bin does): its records must exist for the paths that take those
     }
     __syncthreads();
     const uint32_t T = s_T;   // <= Ta - 1 (split_params_kernel's bound)
+    const bool gathered = gp.rdbase != nullptr && s_over == 0;   // (workgroup-uniform)
     for (uint32_t d = tid; d < nfine; d += NT) {   // the range of every bin: last t with rbin0[t] <= d
         uint32_t lo = 0, hi = T;
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (rbin0[mid] <= d) lo = mid; else hi = mid; }
@@ -797,6 +827,112 @@ __global__ __launch_bounds__(kDirectThreads) void direct_plan_kernel(
         if (t < T) cursor[t] = 0;
     }
     __syncthreads();
+    if (gathered) {
+        // ---- 3g. run descriptors (see above) ----
+        constexpr uint32_t kAvMax = (uint32_t)((NFINE + 1) * sizeof(uint32_t) / (sizeof(V)));   // A values of a block of chunks: where the histogram was
+        const uint32_t CB = max(1u, min(min((uint32_t)CBL, (uint32_t)kCellsLds / T), kAvMax));
+        const bool multi = nc > CB;
+        V *avs = reinterpret_cast<V *>(hist);
+        uint32_t *nzc = reinterpret_cast<uint32_t *>(nxt), *ncur = rbin0;   // runs of every range (then: their exclusive prefix); runs written so far
+        static_assert(sizeof(nxt) >= (kDirectMaxRanges + 1) * sizeof(uint32_t), "runs per range: where the grouping's chain was");
+        const uint32_t rowbase = (uint32_t)gp.rdbase[h];
+        for (uint32_t t = tid; t <= T; t += NT) { nzc[t] = 0; ncur[t] = 0; }
+        // (the A values of a row of ONE block of chunks are fetched now -- two dependent loads -- and arrive during the walk)
+        if (!multi) { for (uint32_t cl = tid; cl < nc; cl += NT) avs[cl] = a_vals[perm[c0 + cl]]; }
+        __syncthreads();
+        // A: (chunk, range) counts, block by block; runs per range
+        for (uint32_t cb = 0; cb < nc; cb += CB) {
+            const uint32_t nb = min(CB, nc - cb);
+            for (uint32_t x = tid; x < nb * T; x += NT) cellm[x] = 0;
+            uint32_t E = have_E;
+            if (cb != have_cb || nb != have_nb) E = load_block(cb, nb);
+            else __syncthreads();
+            have_cb = cb; have_nb = nb; have_E = E;
+            OSP_PLAN_MARK(1);
+            for_entries(nb, E, [&](uint32_t cl, uint32_t col, bool valid) {
+                const uint32_t key = valid ? __umul24(cl, T) + (uint32_t)lut[col >> sh] : 0xffffffffu;
+                uint32_t runlen;
+                if (wave_run_head(key, valid, runlen, above)) atomicAdd(&cellm[key], runlen);
+            });
+            __syncthreads();
+            OSP_PLAN_MARK(4);
+            for (uint32_t x = tid; x < nb * T; x += NT) {
+                const uint32_t c = cellm[x], cl = x / T, t = x - cl * T;
+                if (c) atomicAdd(&nzc[t], 1u);
+                if (multi) rb[lutw + (uint64_t)(cb + cl) * Ta + t] = c;
+            }
+            __syncthreads();
+        }
+        {
+            const uint32_t v = tid < T ? nzc[tid] : 0u;
+            uint32_t total;
+            const uint32_t ex = block_excl_scan<uint32_t, NT>(v, scratch, &total);
+            if (tid < T) nzc[tid] = ex;
+            if (tid == 0) {
+                nzc[T] = total;
+                gp.rowruns[h] = total;
+            }
+        }
+        __syncthreads();
+        for (uint32_t t = tid; t < Ta; t += NT) {
+            const uint64_t v = vbase[h] + t;
+            gp.vrun_off[v] = rowbase + nzc[min(t, T)];
+            gp.vrun_end[v] = rowbase + nzc[min(t + 1, T)];
+        }
+        // B: prefixes and descriptors, block by block
+        const uint32_t G = max(1u, min((uint32_t)NT / T, 16u));
+        for (uint32_t cb = 0; cb < nc; cb += CB) {
+            const uint32_t nb = min(CB, nc - cb);
+            if (multi) {
+                if (cb != have_cb || nb != have_nb) { have_E = load_block(cb, nb); have_cb = cb; have_nb = nb; }
+                for (uint32_t x = tid; x < nb * T; x += NT) { const uint32_t cl = x / T, t = x - cl * T; cellm[x] = rb[lutw + (uint64_t)(cb + cl) * Ta + t]; }
+            }
+            if (multi) { for (uint32_t cl = tid; cl < nb; cl += NT) avs[cl] = a_vals[perm[c0 + cb + cl]]; }
+            __syncthreads();
+            for (uint32_t cl = tid; cl < nb; cl += NT) {   // where every range starts inside its chunk
+                uint32_t run = 0;
+                for (uint32_t t = 0; t < T; t++) { lsm[cl * T + t] = run; run += cellm[cl * T + t]; }
+            }
+            const uint32_t S = (nb + G - 1) / G;
+            for (uint32_t t0 = 0; t0 < T; t0 += NT) {
+                const uint32_t Tb = min((uint32_t)NT, T - t0);
+                const uint32_t g = tid / Tb, t = t0 + (tid - g * Tb);
+                const bool on = g < G;
+                uint32_t run0 = 0, nrun0 = 0;
+                __syncthreads();
+                if (on) {
+                    uint32_t sum = 0, nz = 0;   // (a range holds at most `cap` products, a block at most CBL chunks: 16 bits each)
+                    for (uint32_t cl = g * S; cl < min(nb, (g + 1) * S); cl++) { const uint32_t c = cellm[cl * T + t]; sum += c; nz += c != 0; }
+                    psum[tid] = sum | (nz << 16);
+                    run0 = cursor[t];
+                    nrun0 = ncur[t];
+                }
+                __syncthreads();
+                if (on) {
+                    uint32_t run = run0, nrun = nrun0;
+                    for (uint32_t gg = 0; gg < g; gg++) { const uint32_t p = psum[gg * Tb + (t - t0)]; run += p & 0xffffu; nrun += p >> 16; }
+                    const uint32_t rbase = q0 + roff[t];
+                    RunDesc<V> *__restrict__ out = runs + rowbase + nzc[t];
+                    for (uint32_t cl = g * S; cl < min(nb, (g + 1) * S); cl++) {
+                        const uint32_t c = cellm[cl * T + t];
+                        if (c) {
+                            RunDesc<V> rd;
+                            rd.dst = rbase + run;
+                            rd.src = cbs[cl] + cst[cl] + lsm[cl * T + t];
+                            rd.av = avs[cl];
+                            out[nrun++] = rd;
+                        }
+                        run += c;
+                    }
+                    if (g == G - 1) { cursor[t] = run; ncur[t] = nrun; }
+                }
+            }
+            for (uint32_t cl = tid; cl < nb; cl += NT) chunk_off[perm[c0 + cb + cl]] = kChunkSkip;
+            __syncthreads();
+            OSP_PLAN_MARK(5);
+        }
+        return;
+    }
     for (uint32_t d = tid; d < lutw * 4; d += NT) reinterpret_cast<uint8_t *>(rb)[d] = d < nfine ? lut[d] : (uint8_t)0;
     OSP_PLAN_MARK(3);   // grouping, segment tables
     // ---- 3. cells, a block of chunks at a time

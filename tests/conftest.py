@@ -73,23 +73,29 @@ def _ctx_shared():
     c.close()
 
 
-@pytest.fixture(params=["outer", "rowwise", "outer-split"])
+_VARIANT_ENV = {"outer-split": ("OSP_DIRECT", "0"), "outer-written": ("OSP_GATHER", "0")}
+
+
+@pytest.fixture(params=["outer", "rowwise", "outer-split", "outer-written"])
 def ctx(request, _ctx_shared):
-    """Every test that multiplies runs once per formulation (osp_config_t.algorithm): outer product with staging, and the
-    row-wise variant that forms short rows inside the merge kernel -- both with long rows written straight into their
-    column ranges by the multiply phase ("direct" rows, the default) -- and the outer product with every long row split
-    after the multiply instead (OSP_DIRECT=0).  All must equal the oracle bit for bit.
+    """Every test that multiplies runs once per formulation: the outer product with its planned long rows GATHERED -- never
+    written: the merge kernel forms their partial products from the plan's run descriptors (the default since round 5) --,
+    the same with those rows written into their column ranges by the multiply phase (OSP_GATHER=0: "direct" rows as until
+    round 4, still the path of rows with an over-long range), the row-wise variant that forms short rows inside the merge
+    kernel (osp_config_t.algorithm; its long rows are written), and the outer product with every long row split after the
+    multiply instead (OSP_DIRECT=0).  All must equal the oracle bit for bit.
 
     ONE library context (device 0: stream + buffer pool) for the whole session: a process normally keeps one, and a
     context per test module only meant freeing every pooled device buffer and allocating it again a moment later."""
-    _ctx_shared.algorithm = "outer" if request.param == "outer-split" else request.param
-    had = os.environ.get("OSP_DIRECT")
-    if request.param == "outer-split":
-        os.environ["OSP_DIRECT"] = "0"
+    _ctx_shared.algorithm = "rowwise" if request.param == "rowwise" else "outer"
+    env = _VARIANT_ENV.get(request.param)
+    had = os.environ.get(env[0]) if env else None
+    if env:
+        os.environ[env[0]] = env[1]
     yield _ctx_shared
     _ctx_shared.algorithm = "outer"
-    if request.param == "outer-split":
+    if env:
         if had is None:
-            os.environ.pop("OSP_DIRECT", None)
+            os.environ.pop(env[0], None)
         else:
-            os.environ["OSP_DIRECT"] = had
+            os.environ[env[0]] = had
