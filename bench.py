@@ -561,13 +561,27 @@ def kernel_roofline(infos, n, E, serial=None):
     nmul = max(1, info["multiply_launches"])
     nmer = max(1, minfo["merge_launches"])
     nrows = int(minfo.get("M", n))
-    mul_bytes = (E * (nnz_al + info["nnz_b"]) + 2 * 8 * (n + 1) + E * Pl) / nmul
-    mer_bytes = (E * minfo["partials"] + E * minfo["nnz_c"] + 8 * (nrows + 1)) / nmer
+    # Gathered rows: the merge kernel forms their partial products itself -- for the share g of the products it
+    # does the multiply phase's work too, and is priced on both phases' algorithmic bytes for that share (a design
+    # that does not spill partials is still scored against the two-phase figure); the multiply kernel on the rest.
+    g = (minfo.get("gathered_partials", 0) + minfo.get("gathered_short_partials", 0)) / max(1, minfo["partials"])
+    mul_model = E * (nnz_al + info["nnz_b"]) + 2 * 8 * (n + 1) + E * Pl
+    mul_bytes = (1.0 - g) * mul_model / nmul
+    mer_only = (E * minfo["partials"] + E * minfo["nnz_c"] + 8 * (nrows + 1)) / nmer
+    mer_bytes = mer_only + g * mul_model / nmer
     for name, nbytes, ms, nl in (("multiply_kernel", mul_bytes, mean("ms_multiply_kernel"), nmul),
                                  ("merge_tiles_kernel", mer_bytes, mean("ms_merge_kernel", tinfos), nmer)):
         per = ms / nl
         kernels[name] = {"algorithmic_bytes_per_launch": nbytes, "ms_per_launch": per, "launches_per_step": nl,
                          "GBps": (nbytes / (per * 1e-3) / 1e9) if per > 0 else 0.0}
+    if g > 0:
+        k = kernels["merge_tiles_kernel"]
+        k["gathered_share_of_partials"] = g
+        k["what"] = ("multiply + merge of the gathered rows, merge of the rest: priced on the merge phase's bytes plus the gathered share of "
+                     "the multiply phase's; merge phase alone: algorithmic_bytes_merge_phase_only / GBps_merge_phase_only")
+        k["algorithmic_bytes_merge_phase_only"] = mer_only
+        k["GBps_merge_phase_only"] = (mer_only / (k["ms_per_launch"] * 1e-3) / 1e9) if k["ms_per_launch"] > 0 else 0.0
+        kernels["multiply_kernel"]["what"] = "the rows that are still written: the share 1 - g of the multiply phase's bytes"
     if minfo.get("split_launches"):
         # the one-workgroup split of long rows: two reads and one write of every record it moves
         nsp = minfo["split_launches"]
@@ -575,6 +589,13 @@ def kernel_roofline(infos, n, E, serial=None):
         nbytes = 3.0 * E * minfo["split_partials"] / nsp
         kernels["split_row_kernel"] = {"algorithmic_bytes_per_launch": nbytes, "ms_per_launch": per, "launches_per_step": nsp,
                                        "GBps": (nbytes / (per * 1e-3) / 1e9) if per > 0 else 0.0}
+    if info.get("expand_launches"):
+        # the long rows beyond the planner, staged row by row: B's entries read (gathered), the records written
+        nx = info["expand_launches"]
+        per = mean("ms_expand_kernel") / nx
+        nbytes = 2.0 * E * info["expand_partials"] / nx
+        kernels["expand_rows_kernel"] = {"algorithmic_bytes_per_launch": nbytes, "ms_per_launch": per, "launches_per_step": nx,
+                                         "GBps": (nbytes / (per * 1e-3) / 1e9) if per > 0 else 0.0}
     if minfo.get("direct_plan_launches"):
         # the plan of the direct rows: B's column indices of every such row read twice (histogram, cells); what it writes
         # (one word per chunk and range) is small beside that
@@ -858,6 +879,10 @@ def main():
             "long_rows": info["heavy_rows"], "long_row_partials": info["heavy_partials"],
             # long rows the multiply wrote straight into their column ranges (no split pass), and the ones split afterwards
             "long_rows_direct": info["direct_rows"], "long_row_partials_direct": info["direct_partials"],
+            # of those, the rows that were never written: the merge kernel formed their partial products from the plan's run
+            # descriptors; and the short rows formed the same way
+            "long_rows_gathered": info["gathered_rows"], "long_row_partials_gathered": info["gathered_partials"],
+            "run_descriptors": info["gathered_runs"], "short_row_partials_gathered": info["gathered_short_partials"],
             # rows beyond the one-workgroup planner that the multiply wrote into uniform column blocks (no stretch split)
             "long_rows_hub": info["hub_rows"], "long_row_partials_hub": info["hub_partials"], "hub_cells": info["hub_cells"],
             "long_row_partials_split_by_one_workgroup": info["split_partials"],
@@ -887,6 +912,7 @@ def main():
         # measurement: simulated cycles of a 256-PE OuterSPACE at 85 B/cycle of DRAM, and the DRAM bytes it prices
         from outerspace_amd import cost_model
         torch.cuda.synchronize()
+        ctx.trim()   # the library's pool may hold every free byte of the device: torch needs a few hundred MB for this
         pred = cost_model.analytical(csc[0], csc[1], csr[0], value_size=np.dtype(np_dtype).itemsize)
         note("cost model evaluated")
         pred["note"] = ("OuterSPACE analytical model restated from the reference (not a measurement): cycles of the "

@@ -130,6 +130,12 @@ typedef struct osp_result_info {
                                    products itself, tile by tile, from the plan's run descriptors (cscMulcsr inside the merge) */
     uint64_t gathered_partials; /* partial products in those rows */
     uint64_t gathered_runs;     /* run descriptors planned for them: one per non-empty (chunk, column range) cell */
+    uint64_t gathered_short_partials; /* partial products of the rows that fit a merge tile, formed the same way (their runs are
+                                   their chunks); 0: those rows were staged by the multiply phase */
+    float ms_expand_kernel;     /* since version 5: expand_rows_kernel launches alone -- the long rows beyond the planner, staged row by
+                                   row from the chunk table when everything else is gathered */
+    uint32_t expand_launches;
+    uint64_t expand_partials;   /* partial products those launches wrote */
 } osp_result_info_t;
 
 /* ---- context ------------------------------------------------------------------------- */

@@ -49,7 +49,9 @@ class ResultInfo(C.Structure):
                 ("rank_atomic", C.c_uint32), ("dense_atomic", C.c_uint32), ("hub_rows", C.c_uint64), ("hub_partials", C.c_uint64), ("hub_cells", C.c_uint64),
                 ("ms_hub_plan_kernel", C.c_float), ("hub_plan_launches", C.c_uint32),
                 ("output_slack_bytes", C.c_uint64), ("plans_overlapped", C.c_uint64),
-                ("gathered_rows", C.c_uint64), ("gathered_partials", C.c_uint64), ("gathered_runs", C.c_uint64)]
+                ("gathered_rows", C.c_uint64), ("gathered_partials", C.c_uint64), ("gathered_runs", C.c_uint64),
+                ("gathered_short_partials", C.c_uint64), ("ms_expand_kernel", C.c_float), ("expand_launches", C.c_uint32),
+                ("expand_partials", C.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

@@ -263,12 +263,12 @@ struct Result {
 
 struct PhaseTimer {
     hipStream_t s;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[9];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[10];
     explicit PhaseTimer(hipStream_t st) : s(st) {}
     ~PhaseTimer() {
         for (auto &v : ev) for (auto &p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     }
-    hipStream_t on[9] = {};   // the stream the open interval of a phase was begun on (a panel's plan may run on the second stream)
+    hipStream_t on[10] = {};   // the stream the open interval of a phase was begun on (a panel's plan may run on the second stream)
     void begin(int ph, hipStream_t st = nullptr) {
         hipEvent_t a, b;
         OSP_HIP(hipEventCreate(&a));
@@ -296,7 +296,7 @@ struct EventPair {
     EventPair &operator=(const EventPair &) = delete;
     float ms() const { float t = 0; (void)hipEventElapsedTime(&t, a, b); return t; }
 };
-enum { PH_SYM = 0, PH_MUL = 1, PH_MERGE = 2, PH_COMPACT = 3, PH_MUL_K = 4, PH_MERGE_K = 5, PH_SPLIT_K = 6, PH_PLAN_K = 7, PH_HUB_K = 8 };
+enum { PH_SYM = 0, PH_MUL = 1, PH_MERGE = 2, PH_COMPACT = 3, PH_MUL_K = 4, PH_MERGE_K = 5, PH_SPLIT_K = 6, PH_PLAN_K = 7, PH_HUB_K = 8, PH_EXPAND_K = 9 };
 
 // debugging aid: OSP_SYNC=1 waits for the stream at the marked points of a product and names them on stderr, so
 // that an asynchronous GPU fault is pinned to the step that caused it (the last name printed COMPLETED)
@@ -519,9 +519,11 @@ template <class T> struct Producer {
     // (cells / qstage: the plan and the second buffer of the panel's direct rows, osp_kernels.h store_direct; null
     // when the panel has none)
     // (hub: cells and run table of the panel's hub rows, osp_kernels.h "HUB rows"; null when the panel has none)
+    // (compact: the panel has gathered rows -- chunks nobody writes; osp_kernels.h, multiply_kernel IND;
+    //  has_long: it has rows longer than a tile)
     virtual void produce(uint64_t r0, uint64_t r1, bool whole, uint64_t base, uint64_t count,
                          Part<T> *stage, PhaseTimer &tm, const uint32_t *cells = nullptr, Part<T> *qstage = nullptr,
-                         const HubArgs *hub = nullptr) = 0;
+                         const HubArgs *hub = nullptr, bool compact = false, bool has_long = true, bool desc_only = false) = 0;
 };
 
 // ---- rows of partial products -> merged rows -------------------------------------------------------
@@ -532,6 +534,11 @@ template <class T> struct MergeIO {
     const uint64_t *out_in; uint64_t *out_out;    // entries written before / after this call (device)
     ChunkTable<T> ct{};                           // row-wise variant: rows that fit a tile are computed in the tile kernel
     uint32_t *abort_word = nullptr;               // set by a look-back that gave up (merge_tiles_kernel): the product is an error
+    // gathered short rows (osp_kernels.h, GatherArgs): their run table, the first run of every row, B (null: they are staged)
+    const RunDesc<T> *runs0 = nullptr; const uint32_t *rowfirst0 = nullptr; const uint32_t *b_colidx = nullptr; const T *b_vals = nullptr;
+};
+template <class T> struct ShortRuns {
+    const RunDesc<T> *runs0 = nullptr; const uint32_t *rowfirst0 = nullptr; const uint32_t *b_colidx = nullptr; const T *b_vals = nullptr;
 };
 
 struct TilePlan {
@@ -592,6 +599,7 @@ struct DirectSrc {
     // gathered rows (osp_kernels.h): direct rows without an over-long range are not written by the multiply at all; the tile
     // kernel forms their records from run descriptors.  a_vals: indexed by `perm`; gstat: rows / partial products / runs (device)
     bool gather = false;
+    bool expand_rows = false;   // the short rows are gathered too: plainly staged long rows are expanded row by row (expand_rows_kernel)
     const void *a_vals = nullptr, *b_vals = nullptr;
     unsigned long long *gstat = nullptr;
 };
@@ -616,6 +624,10 @@ template <class T> struct PanelPlan {
     HubArgs hub{};                    // hub rows: (chunk, run) cells and B's run table; cells == nullptr: the panel has none
     GatherArgs<T> ga{};               // gathered rows: the run table (runs == nullptr: the panel has none) ...
     uint32_t *vrun_off = nullptr, *vrun_end = nullptr;   // ... and every segment's descriptors in it
+    uint32_t *nwritten = nullptr;     // direct rows that are not gathered (device; 0: only the hub rows need the column-major multiply)
+    uint64_t *xjobbase = nullptr;     // expand_rows_kernel's jobs: first job of every long row (null: the multiply stages the rows)
+    uint64_t xjobs_bound = 0, xpartials = 0;
+    bool expand_ok = false;           // the panel's plainly staged long rows (if any) have jobs: the column-major multiply need not stage them
     explicit PanelPlan(Context *c) : sc(c) {}
 };
 
@@ -755,6 +767,9 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
             gp.rdbase = rdbase; gp.vrun_off = pl.vrun_off; gp.vrun_end = pl.vrun_end;
             gp.rowruns = sc.get<uint32_t>(nlong);
             OSP_HIP(hipMemsetAsync(gp.rowruns, 0xff, (uint64_t)nlong * sizeof(uint32_t), s));
+            pl.nwritten = gp.nwritten = sc.get<uint32_t>(1);
+            zero_async(s, {{pl.nwritten, sizeof(uint32_t)}});
+            gp.over = !(getenv("OSP_GATHER_OVER") && atoi(getenv("OSP_GATHER_OVER")) == 0);
             pl.ga.runs = runs; pl.ga.b_colidx = ds->b_colidx; pl.ga.b_vals = (const T *)ds->b_vals;
         }
         tm.begin(PH_PLAN_K, s);
@@ -845,6 +860,20 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
         }
         dbg_sync(s, "plan of the hub rows");
     }
+    // With the short rows gathered, the long rows that are staged plainly -- split rows, stretch rows unless they are hub rows -- are
+    // expanded row by row (expand_rows_kernel) instead of column by column: their jobs.
+    if (ds && ds->expand_rows) {
+        pl.expand_ok = true;
+        const bool hubs = pl.hub.cells != nullptr;
+        const uint64_t rows_x = pl.mode_rows[kModeSplitRow] + (hubs ? 0 : pl.mode_rows[kModeStretch]);
+        pl.xpartials = pl.mode_partials[kModeSplitRow] + (hubs ? 0 : pl.mode_partials[kModeStretch]);
+        if (rows_x) {
+            pl.xjobbase = sc.get<uint64_t>((uint64_t)nlong + 1);
+            device_exclusive_scan<ExpandJobs, uint64_t>(ExpandJobs{pl.p0.long_rows, row_off, pl.hmode, kModeSplitRow, hubs ? kModeSplitRow : kModeStretch},
+                                                        nlong, pl.xjobbase, pl.hscan_tmp, s);
+            pl.xjobs_bound = pl.xpartials / kExpandJob + rows_x;
+        }
+    }
 }
 
 // One panel after the multiply: long rows that are not direct are split into column-range segments; the tiles of all
@@ -915,6 +944,10 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
             seg_src = sc.get<uint64_t>(nseg_long);
             seg_nnz = sc.get<uint32_t>(nvirt + 1);
             lv.heavy_nnz[1] = seg_nnz;
+            // over-long segments of gathered rows: their records, from their runs (the paths below read records)
+            if (pl.ga.runs)
+                expand_segments_kernel<T><<<nseg_long, kExpandThreads, 0, s>>>(p1.long_rows, nseg_long, vrow_off, pl.vrun_off, pl.vrun_end, pl.ga.runs,
+                                                                              pl.ga.b_colidx, pl.ga.b_vals, qstage);
             // first those whose column range is narrow (hub rows): one dense accumulator per column, no sort at all
             // (debugging aid: OSP_DENSE_SEG=0 leaves them to the two paths below)
             const uint32_t *rest_list = p1.long_rows;
@@ -1004,7 +1037,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         ntot = p0.ntiles + (p1.ntiles - nlong);   // (the scan's total: every long row's tiles but one -- no read-back)
         desc = sc.get<TileDesc>(ntot);
         tile_desc_kernel<(int)kCap><<<grid_for(p0.ntiles, 256), 256, 0, s>>>(p0.tile_rows, p0.ntiles, r1, io.row_off, base, 0u, j0, extra,
-                                                                           nlong, tb, pl.vcol0, pl.vcol1, desc);
+                                                                           nlong, tb, pl.vcol0, pl.vcol1, desc, nullptr, nullptr, io.rowfirst0);
         tile_desc_kernel<(int)kCap><<<grid_for(p1.ntiles, 256), 256, 0, s>>>(p1.tile_rows, p1.ntiles, nvirt, vrow_off, 0, 1u, j0, extra,
                                                                            nlong, tb, pl.vcol0, pl.vcol1, desc, pl.ga.runs ? pl.vrun_off : nullptr,
                                                                            pl.vrun_end);
@@ -1012,7 +1045,7 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
     } else {
         desc = sc.get<TileDesc>(ntot);
         tile_desc_kernel<(int)kCap><<<grid_for(p0.ntiles, 256), 256, 0, s>>>(p0.tile_rows, p0.ntiles, r1, io.row_off, base, 0u, nullptr,
-                                                                           nullptr, 0u, nullptr, nullptr, nullptr, desc);
+                                                                           nullptr, 0u, nullptr, nullptr, nullptr, desc, nullptr, nullptr, io.rowfirst0);
     }
     uint64_t *tile_status = sc.get<uint64_t>(ntot);
     // ticket counters: one word, or OSP_MERGE_SHARDS of them plus the arrival counter (osp_kernels.h, take_ticket; measured:
@@ -1029,11 +1062,14 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
         OSP_WITH_RA(ctx, merge_tiles_kernel<T, kMergeThreads, 64, TileCap<T>::value, kMergeMaxWgs, RA>
                     <<<std::min<uint32_t>(ntot, rw_grid), kMergeThreads, 0, s>>>(desc, ntot, lv, colbits, tile_status, ticket, io.out_in, io.c_col,
                                                                                  io.c_val, io.out_out, io.ct, nshards, io.abort_word));
-    } else if (pl.ga.runs) {   // the panel has gathered rows: the instantiation that forms their records
+    } else if (pl.ga.runs || io.runs0) {   // the panel has gathered rows: the instantiation that forms their records
+        GatherArgs<T> ga = pl.ga;
+        ga.runs0 = io.runs0;
+        if (io.runs0) { ga.b_colidx = io.b_colidx; ga.b_vals = io.b_vals; }
         const uint32_t merge_grid = ctx->cus * (uint32_t)merge_wgs_per_cu<T, kMergeThreads, TileCap<T>::value>();
         OSP_WITH_RA(ctx, merge_tiles_kernel<T, kMergeThreads, 0, TileCap<T>::value, kMergeMaxWgs, RA, true>
                     <<<std::min<uint32_t>(ntot, merge_grid), kMergeThreads, 0, s>>>(desc, ntot, lv, colbits, tile_status, ticket, io.out_in, io.c_col,
-                                                                                    io.c_val, io.out_out, ChunkTable<T>{}, nshards, io.abort_word, pl.ga));
+                                                                                    io.c_val, io.out_out, ChunkTable<T>{}, nshards, io.abort_word, ga));
     } else {
         const uint32_t merge_grid = ctx->cus * (uint32_t)merge_wgs_per_cu<T, kMergeThreads, TileCap<T>::value>();
         OSP_WITH_RA(ctx, merge_tiles_kernel<T, kMergeThreads, 0, TileCap<T>::value, kMergeMaxWgs, RA>
@@ -1042,6 +1078,39 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
     }
     tm.end(PH_MERGE_K);
     dbg_sync(s, "merge tiles");
+#ifdef OSP_MERGE_PROF
+    if (getenv("OSP_VERBOSE")) {   // the tiles by sort passes (key bits) and fill
+        std::vector<TileDesc> hd(ntot);
+        copy_d2h(hd.data(), desc, (size_t)ntot * sizeof(TileDesc), s);
+        uint64_t byp[5] = {0}, ent[5] = {0}, gt = 0, ge = 0, gr = 0, bits[33] = {0};
+        for (const TileDesc &t : hd) {
+            if (t.n > kCap) continue;
+            int rb = 0; while ((1u << rb) < t.nr) rb++;
+            const int kb = t.kbits ? (int)t.kbits : colbits + rb;
+            const int np = std::min(4, (kb + kDigitBits - 1) / kDigitBits);
+            byp[np]++; ent[np] += t.n; bits[std::min(kb, 32)] += 1;
+            if (t.rcnt) { gt++; ge += t.n; gr += t.rcnt; }
+        }
+        fprintf(stderr, "[osp]   tiles by sort passes:");
+        for (int k = 0; k < 5; k++) if (byp[k]) fprintf(stderr, " %d passes: %llu tiles, %.0f entries each;", k, (unsigned long long)byp[k], (double)ent[k] / byp[k]);
+        fprintf(stderr, " gathered: %llu tiles, %.0f entries and %.1f runs each\n[osp]   tiles by key bits:", (unsigned long long)gt, gt ? (double)ge / gt : 0.0, gt ? (double)gr / gt : 0.0);
+        for (int k = 0; k <= 32; k++) if (bits[k]) fprintf(stderr, " %d: %llu;", k, (unsigned long long)bits[k]);
+        fprintf(stderr, "\n");
+    }
+    if (getenv("OSP_VERBOSE")) {   // (`make prof`: cycles of thread 0 of every workgroup between the kernel's marks)
+        unsigned long long hp[16] = {0}, z[16] = {0};
+        OSP_HIP(hipStreamSynchronize(s));
+        (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(osp_merge_prof), sizeof(hp));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(osp_merge_prof), z, sizeof(z));
+        static const char *names[12] = {"run table / hash init", "keys + hash count", "publish", "rank", "digit scan", "scatter", "values + heads + scan",
+                                        "look-back + ticket", "run sums", "compaction", "output + next tile's request", "gathered: lookup + columns"};
+        double tot = 0;
+        for (int k = 0; k < 12; k++) tot += (double)hp[k];
+        fprintf(stderr, "[osp]   merge kernel, %u tiles, cycles of thread 0 per phase:", ntot);
+        for (int k = 0; k < 12; k++) fprintf(stderr, " %s %.1f %%;", names[k], 100.0 * hp[k] / tot);
+        fprintf(stderr, " %.0f cycles per tile and workgroup\n", tot / std::max(1u, ntot));
+    }
+#endif
     res->info.merge_launches++;
     if (p1.nlong) {
         heavy_copy_kernel<T><<<grid_for(p1.nlong, 8), 256, 0, s>>>(p1.long_rows, p1.nlong, seg_src, seg_nnz, vptr, qstage, nullptr, nullptr,
@@ -1069,7 +1138,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
                            const uint64_t *d_row_off,
                            uint64_t P, uint64_t cap_cfg, PhaseTimer &tm, uint64_t r_lo = 0, uint64_t r_hi = ~0ull,
                            uint64_t off_lo = 0, const PanelSink *sink = nullptr, const ChunkTable<T> *ct = nullptr,
-                           const DirectSrc *ds = nullptr, const std::vector<uint64_t> *cuts = nullptr) {
+                           const DirectSrc *ds = nullptr, const std::vector<uint64_t> *cuts = nullptr, const ShortRuns<T> *sr = nullptr) {
     // cuts (optional, ascending row ids inside (r_lo, r_hi)): a panel never reaches across one of them -- the multi-GPU
     // merge makes its panels end where the pieces it receives end (osp_multi.h)
     // output rows [r_lo, r_hi) only (row-sharded multi-GPU mode); P = their partial products, off_lo = row_off[r_lo]
@@ -1140,7 +1209,9 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     // what a staged partial product needs: its record in the staging buffer, for 9 of 10 another one in the second buffer,
     // and a few per cent for tile tables and the cells of the direct rows -- 2.0 record sizes; 2.6 budgets 30 % on top of
     // that (3.3 until round 3: R-MAT-22 mild ran as 4 panels, now 3: one panel's planning, launches and read-backs less)
-    const double per_record = getenv("OSP_STAGE_FACTOR") ? atof(getenv("OSP_STAGE_FACTOR")) : (sink ? 3.7 : 2.6);
+    // (round 5, gathered rows: nothing is written for nine records of ten, but both buffers are still addressed by the rows'
+    // positions -- allocated in full -- and the run table is sized by a bound: measured 2.25 record sizes per product; 2.5)
+    const double per_record = getenv("OSP_STAGE_FACTOR") ? atof(getenv("OSP_STAGE_FACTOR")) : (sink ? 3.7 : (ds && ds->gather) ? 2.5 : 2.6);
     if (cap == 0) cap = std::max<uint64_t>((uint64_t)(free_b * 0.85 / (per_record * E)), 1ull << 20);
     cap = std::min<uint64_t>(cap, 0xfffffff0ull);  // staging positions are u32
     if (getenv("OSP_VERBOSE"))
@@ -1236,7 +1307,24 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         const bool beside = overlap && p + 1 < npanels;
         if (beside) OSP_HIP(hipEventRecord(ctx->aux_fork, s));
         tm.begin(PH_MUL);
-        if (count) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm, plan.cells, plan.qstage, plan.hub.cells ? &plan.hub : nullptr);
+        bool column_major = count != 0, desc_only = false;
+        if (count && plan.xjobbase && plan.xjobs_bound) {
+            tm.begin(PH_EXPAND_K);
+            expand_rows_kernel<T><<<(unsigned)plan.xjobs_bound, kExpandThreads, 0, s>>>(plan.p0.long_rows, plan.p0.nlong, plan.xjobbase, d_row_off, base, ds->rowfirst,
+                                                                                     ds->off, ds->bs, ds->perm, (const T *)ds->a_vals, ds->b_colidx,
+                                                                                     (const T *)ds->b_vals, stage);
+            tm.end(PH_EXPAND_K);
+            res->info.expand_launches++;
+            res->info.expand_partials += plan.xpartials;
+        }
+        if (count && plan.expand_ok) {
+            // what is left for the column-major multiply: rows written through cells -- hub rows, direct rows with an over-long range
+            desc_only = true;
+            const uint32_t nw = plan.nwritten ? d2h(plan.nwritten, s) : 0u;
+            column_major = plan.hub.cells != nullptr || nw != 0;
+        }
+        if (column_major) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm, plan.cells, plan.qstage, plan.hub.cells ? &plan.hub : nullptr,
+                                       plan.ga.runs != nullptr, plan.p0.nlong != 0, desc_only);
         tm.end(PH_MUL);
         if (beside) {
             nxt = plan_one(p + 1, true);
@@ -1265,6 +1353,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
             OSP_HIP(hipMemsetAsync(cells, 0, 2 * sizeof(uint64_t), s));
             MergeIO<T> io{stage, d_row_off, r0, r1, base, prow - r0, c_col, c_val, cells, cells + 1};
             if (ct) io.ct = *ct;
+            if (sr) { io.runs0 = sr->runs0; io.rowfirst0 = sr->rowfirst0; io.b_colidx = sr->b_colidx; io.b_vals = sr->b_vals; }
             io.abort_word = abort_word;
             merge_panel<T>(ctx, res, tm, io, colbits, plan);
             tm.end(PH_MERGE);
@@ -1295,6 +1384,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         tm.begin(PH_MERGE);
         MergeIO<T> io{stage, d_row_off, r0, r1, base, res->rowptr - r_lo, c_col, c_val, out_nnz + p, out_nnz + p + 1};
         if (ct) io.ct = *ct;
+        if (sr) { io.runs0 = sr->runs0; io.rowfirst0 = sr->rowfirst0; io.b_colidx = sr->b_colidx; io.b_vals = sr->b_vals; }
         io.abort_word = abort_word;
         merge_panel<T>(ctx, res, tm, io, colbits, plan);
         tm.end(PH_MERGE);
@@ -1342,18 +1432,44 @@ template <class T> struct OuterProducer : Producer<T> {
     const uint64_t *chunk_off;   // (the planner of direct rows rewrites the entries of its chunks, panel by panel)
     int64_t *a_start; uint32_t *a_cnt; uint64_t *prod; uint64_t *prod_off; uint64_t *scan_tmp;
     bool nothing_staged = false;  // row-wise variant and no row is longer than a tile: the tile kernel does it all
+    // panels with gathered rows: the list of A's entries whose chunks are written (null: not prepared -- such a panel walks all of A)
+    uint32_t *kscan = nullptr, *kscan_tmp = nullptr, *elist = nullptr, *cscan = nullptr, *klist = nullptr;
+    uint64_t nnz = 0;
+    bool short_gathered = false;  // the short rows are gathered (their chunks: kChunkSkip): a panel without long rows multiplies nothing
     void produce(uint64_t r0, uint64_t r1, bool whole, uint64_t base, uint64_t count, Part<T> *stage,
-                 PhaseTimer &tm, const uint32_t *cells, Part<T> *qstage, const HubArgs *hub = nullptr) override {
+                 PhaseTimer &tm, const uint32_t *cells, Part<T> *qstage, const HubArgs *hub = nullptr, bool compact = false, bool has_long = true,
+                 bool desc_only = false) override {
         if (nothing_staged) return;
+        if (short_gathered && !has_long) return;
         hipStream_t s = ctx->stream;
         const uint64_t nk = k1 - k0;
-        panel_columns_kernel<<<grid_for(nk, 256), 256, 0, s>>>(a_colptr, a_rowidx, b_rowptr, k0, nk, (uint32_t)r0, r1,
-                                                               whole ? 1 : 0, a_start, a_cnt, prod);
+        const bool ind = (compact || short_gathered) && elist && nnz;
+        if (ind) {
+            const PanelKeepFlag keep{a_rowidx, chunk_off, e0, (uint32_t)r0, r1, desc_only ? 1u : 0u};
+            device_exclusive_scan<PanelKeepFlag, uint32_t>(keep, nnz, kscan, kscan_tmp, s);
+            panel_keep_list_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(keep, kscan, nnz, elist);
+            const PanelKeepColFlag kcf{a_colptr, e0, k0, kscan};
+            device_exclusive_scan<PanelKeepColFlag, uint32_t>(kcf, nk, cscan, kscan_tmp, s);
+            panel_keep_columns_kernel<<<grid_for(nk, 256), 256, 0, s>>>(a_colptr, b_rowptr, k0, nk, e0, kscan, cscan, a_start, a_cnt, prod, klist);
+        } else {
+            panel_columns_kernel<<<grid_for(nk, 256), 256, 0, s>>>(a_colptr, a_rowidx, b_rowptr, k0, nk, (uint32_t)r0, r1,
+                                                                   whole ? 1 : 0, a_start, a_cnt, prod);
+        }
         device_exclusive_scan<LoadU64, uint64_t>(LoadU64{prod}, nk, prod_off, scan_tmp, s);
-        const uint64_t nblocks = (count + kMulPerBlock - 1) / kMulPerBlock;
+        uint64_t nblocks = (count + kMulPerBlock - 1) / kMulPerBlock;
+        if (ind) nblocks = std::min<uint64_t>(nblocks, (uint64_t)ctx->cus * 8);   // (strides over the slices: osp_kernels.h)
         dbg_sync(s, "panel columns + scan");
         tm.begin(PH_MUL_K);
-        if (hub && hub->cells)
+        if (ind && hub && hub->cells)
+            multiply_kernel<T, 2, true><<<(unsigned)nblocks, kMulThreads, 0, s>>>(a_vals, b_colidx, b_vals, b_rowptr, chunk_off, e0,
+                                                                                a_start, a_cnt, prod_off, k0, nk, count, base, stage, cells, qstage, *hub, elist, klist);
+        else if (ind && cells)
+            multiply_kernel<T, 1, true><<<(unsigned)nblocks, kMulThreads, 0, s>>>(a_vals, b_colidx, b_vals, b_rowptr, chunk_off, e0,
+                                                                                a_start, a_cnt, prod_off, k0, nk, count, base, stage, cells, qstage, HubArgs{}, elist, klist);
+        else if (ind)
+            multiply_kernel<T, 0, true><<<(unsigned)nblocks, kMulThreads, 0, s>>>(a_vals, b_colidx, b_vals, b_rowptr, chunk_off, e0,
+                                                                                a_start, a_cnt, prod_off, k0, nk, count, base, stage, nullptr, nullptr, HubArgs{}, elist, klist);
+        else if (hub && hub->cells)
             multiply_kernel<T, 2><<<(unsigned)nblocks, kMulThreads, 0, s>>>(a_vals, b_colidx, b_vals, b_rowptr, chunk_off, e0,
                                                                           a_start, a_cnt, prod_off, k0, nk, count, base, stage, cells, qstage, *hub);
         else if (cells)
@@ -1373,7 +1489,7 @@ template <class T> struct PartsProducer : Producer<T> {
     const int64_t *const *d_rowptrs; const uint32_t *const *d_colidxs; const T *const *d_valss;
     int nparts;
     const uint64_t *row_off;
-    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &, const uint32_t *, Part<T> *, const HubArgs *) override {
+    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &, const uint32_t *, Part<T> *, const HubArgs *, bool, bool, bool) override {
         const uint64_t nr = r1 - r0;
         parts_scatter_kernel<T><<<grid_for(nr * kWave, 256), 256, 0, ctx->stream>>>(d_rowptrs, d_colidxs, d_valss, nparts,
                                                                                     r0, r1, row_off, base, stage);
@@ -1386,7 +1502,7 @@ template <class T> struct RecordPartsProducer : Producer<T> {
     int nparts;
     const uint64_t *row_off;
     const std::function<void(uint64_t, uint64_t)> *before = nullptr;   // called with the panel's rows before its records are read
-    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &, const uint32_t *, Part<T> *, const HubArgs *) override {
+    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &, const uint32_t *, Part<T> *, const HubArgs *, bool, bool, bool) override {
         if (before) (*before)(r0, r1);
         const uint64_t nr = r1 - r0;
         parts_scatter_rec_kernel<T><<<grid_for(nr * kWave, 256), 256, 0, ctx->stream>>>(d_rowptrs, d_recs, nparts, r0, r1, row_off, base, stage);
@@ -1569,24 +1685,34 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     const bool dense_avg = (long double)p_all * 8.0L >= 3.0L * (long double)M * (long double)N;
     const bool direct = nnz && (nnz >= direct_min_nnz || dense_avg) && (uint64_t)nnz_b < 0xffffffffull && nnz < 0xffffffffull && !partials_only &&
                         !(getenv("OSP_DIRECT") && atoi(getenv("OSP_DIRECT")) == 0);
-    const uint64_t direct_max = getenv("OSP_DIRECT_MAX") ? strtoull(getenv("OSP_DIRECT_MAX"), nullptr, 10) : kSplitRowMax;
+    const uint64_t direct_max = std::min<uint64_t>(getenv("OSP_DIRECT_MAX") ? strtoull(getenv("OSP_DIRECT_MAX"), nullptr, 10) : kSplitRowMax,
+                                                   kDirectDenseMax);   // (the planner counts a row's products in 21 bits)
+    // Gathered rows (osp_kernels.h): the merge kernel forms the partial products of planned long rows and of short rows itself,
+    // from run descriptors; on unless OSP_GATHER=0 (debugging aid, A/B timing: every row is then written by the multiply, as
+    // until round 4) or the row-wise variant runs (its tile kernel is another instantiation).  OSP_GATHER=1: long rows only.
+    const int gather_env = getenv("OSP_GATHER") ? atoi(getenv("OSP_GATHER")) : 2;
+    const bool gather_ok = nnz && !rowwise && !partials_only && (uint64_t)nnz_b < 0xffffffffull && nnz < 0xffffffffull;
+    // (short rows: only where long rows are planned too -- a product of a few million non-zeros does not earn the tables back:
+    // web-Google shape 2.09 -> 2.50 ms with them)
+    const bool gather_short = gather_ok && gather_env >= 2 && direct;
+    ShortRuns<T> srun{};
     DirectSrc dsrc{};
     uint32_t n_long_rows = 1;
     if (nnz == 0) {
         OSP_HIP(hipMemsetAsync(row_off, 0, (M + 1) * sizeof(uint64_t), s));
     } else {
         Scratch ss(ctx);
-        Scratch &keep = (rowwise || direct) ? sc : ss;  // the chunk table outlives the symbolic phase
+        Scratch &keep = (rowwise || direct || gather_short) ? sc : ss;  // the chunk table outlives the symbolic phase
         uint32_t *ka = ss.get<uint32_t>(nnz), *pa = ss.get<uint32_t>(nnz), *kb = ss.get<uint32_t>(nnz), *pb = ss.get<uint32_t>(nnz);
         uint32_t *rows_sorted = ss.get<uint32_t>(nnz), *perm = keep.get<uint32_t>(nnz), *w_sorted = ss.get<uint32_t>(nnz);
-        uint32_t *bs_sorted = (rowwise || direct) ? keep.get<uint32_t>(nnz) : nullptr;
+        uint32_t *bs_sorted = (rowwise || direct || gather_short) ? keep.get<uint32_t>(nnz) : nullptr;
         uint32_t *rowfirst = keep.get<uint32_t>(M + 1);
         uint32_t *hist = ss.get<uint32_t>(rs_hist_entries(nnz));
         uint32_t *hist_tmp = ss.get<uint32_t>(scan_scratch_entries(rs_hist_entries(nnz)));
         uint64_t *offs_sorted = keep.get<uint64_t>(nnz + 1);
         uint64_t *scan_tmp = ss.get<uint64_t>(scan_scratch_entries(std::max<uint64_t>(nnz, M + 1)));
         // (row, k) order of A's non-zeros; the last sort pass also looks up each chunk's length
-        const bool table = rowwise || direct;   // keep the chunk table: (length, B row) pairs in `w`
+        const bool table = rowwise || direct || gather_short;   // keep the chunk table: (length, B row) pairs in `w`
         uint32_t *w = ss.get<uint32_t>(table ? 2 * nnz : nnz);
         uint32_t *bs = table ? w : nullptr;
         sym_chunk_len_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(a_colptr, b_rowptr, k0, k1, e0, nnz, w, bs);
@@ -1594,7 +1720,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
                                       SymEpilogue{w, bs, rows_sorted, perm, w_sorted, bs_sorted}, s, ctx->rank_atomic);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{w_sorted}, nnz, offs_sorted, scan_tmp, s);
         sym_row_offsets_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(rows_sorted, offs_sorted, nnz, M, row_off, rowfirst);
-        const uint64_t rw_cap = rowwise ? (uint64_t)TileCap<T>::value : 0ull;
+        const uint64_t rw_cap = (rowwise || gather_short) ? (uint64_t)TileCap<T>::value : 0ull;   // rows the multiply skips
         sym_scatter_offsets_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(perm, offs_sorted, rows_sorted, row_off, rw_cap, nnz, chunk_off);
         // (the product proper reads P together with the size of the result, merge_pipeline: one stream round trip less)
         if (partials_only || rowwise || row_sharded) P = d2h(offs_sorted + nnz, s);
@@ -1604,12 +1730,24 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
             dsrc.b_rowptr = b_rowptr; dsrc.K = K; dsrc.nnz_b = (uint64_t)nnz_b; dsrc.keep = &sc;
             // gathered rows (osp_kernels.h): on unless OSP_GATHER=0 (debugging aid, A/B timing: every direct row is then written
             // by the multiply, as until round 4) or the row-wise variant runs (its tile kernel is another instantiation)
-            dsrc.gather = !rowwise && !(getenv("OSP_GATHER") && atoi(getenv("OSP_GATHER")) == 0);
+            dsrc.gather = gather_ok && gather_env >= 1;
+            dsrc.expand_rows = gather_short && !(getenv("OSP_EXPAND_ROWS") && atoi(getenv("OSP_EXPAND_ROWS")) == 0);
             dsrc.a_vals = a_vals + e0; dsrc.b_vals = b_vals;
             if (dsrc.gather) {
                 dsrc.gstat = (unsigned long long *)sc.get<uint64_t>(3);
                 zero_async(s, {{dsrc.gstat, 3 * sizeof(uint64_t)}});
             }
+        }
+        if (gather_short) {
+            // the short rows' chunks as run descriptors, chunks without entries left out (once per product)
+            const ShortRunFlag sf{offs_sorted, rows_sorted, row_off, rw_cap};
+            uint32_t *cidx = ss.get<uint32_t>(nnz + 1), *cidx_tmp = ss.get<uint32_t>(scan_scratch_entries(nnz + 1));
+            device_exclusive_scan<ShortRunFlag, uint32_t>(sf, nnz, cidx, cidx_tmp, s);
+            RunDesc<T> *runs0 = sc.get<RunDesc<T>>(nnz);   // (bound: every chunk; the count stays on the device)
+            uint32_t *rowfirst0 = sc.get<uint32_t>(M + 1);
+            short_runs_kernel<T><<<grid_for(nnz, 256), 256, 0, s>>>(sf, cidx, nnz, bs_sorted, perm, a_vals + e0, runs0);
+            short_rowfirst_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(rowfirst, cidx, M, rowfirst0);
+            srun = ShortRuns<T>{runs0, rowfirst0, b_colidx, b_vals};
         }
         if (rowwise) {
             ct = ChunkTable<T>{offs_sorted, bs_sorted, perm, rowfirst, a_vals + e0, b_colidx, b_vals, (uint32_t)rw_cap, 1u};
@@ -1631,6 +1769,15 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     prod.prod = sc.get<uint64_t>(nk); prod.prod_off = sc.get<uint64_t>(nk + 1);
     prod.scan_tmp = sc.get<uint64_t>(scan_scratch_entries(nk));
     prod.nothing_staged = rowwise && n_long_rows == 0;
+    prod.short_gathered = gather_short;
+    if ((dsrc.gather || gather_short) && nnz && !partials_only) {
+        prod.nnz = nnz;
+        prod.kscan = sc.get<uint32_t>(nnz + 1);
+        prod.kscan_tmp = sc.get<uint32_t>(scan_scratch_entries(std::max<uint64_t>(nnz, k1 - k0) + 1));
+        prod.elist = sc.get<uint32_t>(nnz);
+        prod.cscan = sc.get<uint32_t>(k1 - k0 + 1);
+        prod.klist = sc.get<uint32_t>(k1 - k0 + 1);
+    }
 
     if (partials_only) {
         // osp_spgemm_partials: the multiply phase alone; offsets and records belong to the result
@@ -1657,11 +1804,12 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     // row-sharded: A holds this rank's rows only, so the staging offsets start at 0 at r_lo and P is the shard's count
     const uint64_t off_lo = 0, P_rows = P;
     merge_pipeline<T>(ctx, res, prod, M, N, row_off, P_rows, cfg.partial_capacity, tm, r_lo, r_hi, off_lo, sink,
-                      rowwise ? &ct : nullptr, (direct && nnz) ? &dsrc : nullptr);
+                      rowwise ? &ct : nullptr, (direct && nnz) ? &dsrc : nullptr, nullptr, gather_short ? &srun : nullptr);
 
     OSP_HIP(hipEventRecord(ev.b, s));
     OSP_HIP(hipStreamSynchronize(s));
     const float ms = ev.ms();
+    if (gather_short) res->info.gathered_short_partials = res->info.partials - res->info.heavy_partials;
     if (dsrc.gstat && res->info.direct_rows) {
         uint64_t gs[3] = {0, 0, 0};
         copy_d2h(gs, dsrc.gstat, sizeof(gs), s);
@@ -1681,6 +1829,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     res->info.ms_split_kernel = tm.total(PH_SPLIT_K);
     res->info.ms_direct_plan_kernel = tm.total(PH_PLAN_K);
     res->info.ms_hub_plan_kernel = tm.total(PH_HUB_K);
+    res->info.ms_expand_kernel = tm.total(PH_EXPAND_K);
 }
 
 // COO (device arrays, any order) -> compressed by `seg` with ascending `inner` indices; all outputs in `sc`.

@@ -281,6 +281,44 @@ struct LoadU64 {
     const uint64_t *p;
     __device__ uint64_t operator()(uint64_t i) const { return p[i]; }
 };
+// A panel with gathered rows multiplies a compacted A (multiply_kernel, IND): entry e0 + t is KEPT when its row is in the
+// panel and its chunk is written (not kChunkSkip); elist = the kept entries in CSC order, and per column the window of the list.
+// (desc_only: only the chunks that carry a descriptor -- rows written through cells; the plainly staged rows of such a panel
+// are expanded row by row, expand_rows_kernel)
+struct PanelKeepFlag {
+    const uint32_t *a_rowidx; const uint64_t *chunk_off; int64_t e0; uint32_t r0; uint64_t r1; uint32_t desc_only;
+    __device__ uint32_t operator()(uint64_t t) const {
+        const uint32_t r = a_rowidx[(uint64_t)e0 + t];
+        if (!(r >= r0 && (uint64_t)r < r1)) return 0u;
+        const uint64_t off = chunk_off[t];
+        return (off != ~0ull && (!desc_only || (off >> 63))) ? 1u : 0u;
+    }
+};
+__global__ void panel_keep_list_kernel(PanelKeepFlag f, const uint32_t *kscan, uint64_t nnz, uint32_t *elist) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nnz && f(t)) elist[kscan[t]] = (uint32_t)((uint64_t)f.e0 + t);
+}
+// ... the columns that keep entries, compacted: column number cscan[t] of the list is k0 + t (cscan: exclusive scan of the flags)
+struct PanelKeepColFlag {
+    const int64_t *a_colptr; int64_t e0; uint64_t k0; const uint32_t *kscan;
+    __device__ uint32_t operator()(uint64_t t) const { return kscan[a_colptr[k0 + t + 1] - e0] != kscan[a_colptr[k0 + t] - e0] ? 1u : 0u; }
+};
+__global__ void panel_keep_columns_kernel(const int64_t *a_colptr, const int64_t *b_rowptr, uint64_t k0, uint64_t nk, int64_t e0,
+                                          const uint32_t *kscan, const uint32_t *cscan, int64_t *a_start, uint32_t *a_cnt, uint64_t *prod,
+                                          uint32_t *klist) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nk) return;
+    const uint64_t k = k0 + t;
+    const uint32_t lo = kscan[a_colptr[k] - e0], hi = kscan[a_colptr[k + 1] - e0];
+    const uint32_t ncol = cscan[nk];   // columns in the list; the entries behind them: no products, column k0
+    if (t >= ncol) { a_start[t] = 0; a_cnt[t] = 0; prod[t] = 0; klist[t] = (uint32_t)k0; }
+    if (hi == lo) return;
+    const uint32_t j = cscan[t];
+    a_start[j] = (int64_t)lo;
+    a_cnt[j] = hi - lo;
+    prod[j] = (uint64_t)(hi - lo) * (uint64_t)(b_rowptr[k + 1] - b_rowptr[k]);
+    klist[j] = (uint32_t)k;
+}
 
 // value of lane `src` (wave-uniform index) for every lane
 __device__ __forceinline__ uint32_t wave_bcast(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }
@@ -429,17 +467,26 @@ __device__ __forceinline__ void chunk_dests(const uint32_t *__restrict__ cells, 
 // DIRECT: the launch has direct rows (descriptors among the chunk offsets); without them the kernel is instantiated without
 // that code (64 registers instead of 68: one more wave per SIMD, which the products of short rows notice)
 // MODE: 0 = no direct rows in the launch, 1 = direct rows, 2 = direct rows and hub rows (descriptors with the hub marker)
-template <class T, int MODE = 1>
+// IND: a panel with gathered rows (their chunks are never written: most of the headline's products).  Walking the skipped
+// chunks costs the multiply what writing them would in instructions (11 ms per launch for a seventh of the records), so such a
+// panel multiplies a COMPACTED A: `elist` holds, column after column, the entries of A whose chunks are written (panel_keep_*
+// below); a_start / a_cnt / prod_off count in that list, and `total` is read from the scan (the launch covers the panel's
+// full count: the workgroups beyond the written products leave at once).
+template <class T, int MODE = 1, bool IND = false>
 __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
     const T *__restrict__ a_vals, const uint32_t *__restrict__ b_colidx, const T *__restrict__ b_vals,
     const int64_t *__restrict__ b_rowptr, const uint64_t *__restrict__ chunk_off, int64_t e0,
     const int64_t *__restrict__ a_start, const uint32_t *__restrict__ a_cnt,
     const uint64_t *__restrict__ prod_off, uint64_t k0, uint64_t nk, uint64_t total, uint64_t base,
     Part<T> *__restrict__ stage, const uint32_t *__restrict__ cells = nullptr, Part<T> *__restrict__ qstage = nullptr,
-    const HubArgs hub = HubArgs{}) {
+    const HubArgs hub = HubArgs{}, const uint32_t *__restrict__ elist = nullptr, const uint32_t *__restrict__ klist = nullptr) {
     constexpr bool DIRECT = MODE != 0;
     const unsigned lane = lane_id();
-    const uint64_t wv = (uint64_t)blockIdx.x * (kMulThreads / kWave) + (threadIdx.x >> 6);
+    // (IND: the host does not know how many products are written -- a count on the device -- and a grid for the panel's full
+    // count would be workgroups that leave at once, half a million of them: 4 ms of dispatch for nothing.  A fixed grid
+    // strides over the slices instead.)
+    if constexpr (IND) total = prod_off[nk];
+    for (uint64_t wv = (uint64_t)blockIdx.x * (kMulThreads / kWave) + (threadIdx.x >> 6);; wv += (uint64_t)gridDim.x * (kMulThreads / kWave)) {
     const uint64_t ws = wv * kMulPerWave;
     if (ws >= total) return;
     const uint64_t we = min(ws + (uint64_t)kMulPerWave, total);
@@ -463,8 +510,12 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
             const uint64_t pe = prod_off[min(kk + lane + 1, nk)] - p0;
             // (a column whose B row is numbered in panels -- below -- never joins a batch: the waves that share a column
             // must agree on the numbering of its products, and the batch walk numbers them chunk by chunk)
-            const uint64_t bs_l = (uint64_t)b_rowptr[k0 + min(kk + lane, nk - 1)];
-            const uint32_t nb_l = (uint32_t)((uint64_t)b_rowptr[k0 + min(kk + lane, nk - 1) + 1] - bs_l);
+            // (IND: the columns are the panel's columns WITH written products, klist names them -- between two of them lie
+            // thousands that have none, and finding the next one through their zero counts cost a bisection of 22 dependent loads)
+            uint64_t kcol = k0 + min(kk + lane, nk - 1);
+            if constexpr (IND) kcol = klist[min(kk + lane, nk - 1)];
+            const uint64_t bs_l = (uint64_t)b_rowptr[kcol];
+            const uint32_t nb_l = (uint32_t)((uint64_t)b_rowptr[kcol + 1] - bs_l);
             const uint64_t fits = __ballot(kk + lane < nk && pe <= (uint64_t)kMulBatchMax && nb_l < (uint32_t)kMulTileMin);
             const uint32_t ncol = fits == ~0ull ? (uint32_t)kWave : (uint32_t)__builtin_ctzll(~fits);  // pe ascends: a prefix of lanes
             // (and only where the columns are small on average: with B's row in registers the per-column path below is the
@@ -494,7 +545,8 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                     const uint64_t asx = (uint64_t)__shfl((long long)asq, (int)lo);
                     if (x < hi_p) {
                         const uint32_t j = r / nbx, l = r - j * nbx;
-                        const uint64_t e = asx + j;
+                        uint64_t e = asx + j;
+                        if constexpr (IND) e = elist[e];
                         const uint64_t raw = chunk_off[e - (uint64_t)e0];
                         const uint32_t bc = b_colidx[bsx + l];
                         const T pv = a_vals[e] * b_vals[bsx + l];
@@ -509,7 +561,8 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                 continue;
             }
         }
-        const uint64_t k = k0 + kk;
+        uint64_t k = k0 + kk;
+        if constexpr (IND) k = klist[kk];
         const uint64_t bs = (uint64_t)b_rowptr[k];
         const uint32_t nb = (uint32_t)((uint64_t)b_rowptr[k + 1] - bs);
         const uint64_t as = (uint64_t)a_start[kk];
@@ -555,8 +608,10 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                     T av_l = 0;
                     uint64_t off_l = kChunkSkip;
                     if (jm <= tj1) {
-                        av_l = a_vals[as + jm];
-                        const uint64_t raw = chunk_off[as + jm - (uint64_t)e0];
+                        uint64_t e = as + jm;
+                        if constexpr (IND) e = elist[e];
+                        av_l = a_vals[e];
+                        const uint64_t raw = chunk_off[e - (uint64_t)e0];
                         off_l = ((raw & kDirectBit) && (DIRECT || raw == kChunkSkip)) ? raw : raw - base + (uint64_t)pnl * W;  // (kChunkSkip and descriptors: as they are)
                     }
                     const uint32_t cj = (uint32_t)min((uint64_t)kWave, tj1 - jb + 1);
@@ -597,8 +652,10 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                 T av_l = 0;
                 uint64_t off_l = kChunkSkip;
                 if (jm <= j1) {
-                    av_l = a_vals[as + jm];
-                    const uint64_t raw = chunk_off[as + jm - (uint64_t)e0];
+                    uint64_t e = as + jm;
+                    if constexpr (IND) e = elist[e];
+                    av_l = a_vals[e];
+                    const uint64_t raw = chunk_off[e - (uint64_t)e0];
                     off_l = ((raw & kDirectBit) && (DIRECT || raw == kChunkSkip)) ? raw : raw - base;  // (kChunkSkip and descriptors: as they are)
                 }
                 const uint32_t cj = (uint32_t)min((uint64_t)kWave, j1 - jb + 1);
@@ -643,7 +700,8 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
                 const uint64_t j = jb + jj;
                 bool ok = in && j <= j1 && !(j == j0 && l < la) && !(j == j1 && l >= lb);
                 if (ok) {
-                    const uint64_t e = as + j;
+                    uint64_t e = as + j;
+                    if constexpr (IND) e = elist[e];
                     const uint64_t raw = chunk_off[e - (uint64_t)e0];
                     if (raw != kChunkSkip) {
                         if (DIRECT && (raw & kDirectBit)) store_direct<T, MODE>(cells, hub, qstage, raw, bs, l, bc, a_vals[e] * bv);
@@ -653,6 +711,87 @@ __global__ __launch_bounds__(kMulThreads) void multiply_kernel(
             }
         }
         cur = p0 + b;
+    }
+    if constexpr (!IND) return;
+    }
+}
+
+// ---- long rows that are staged, row by row ----------------------------------------------------------------------------------
+// With the short rows and the planned long rows gathered, what is left to stage are the long rows beyond the planner (a few
+// hundred hub rows per panel in R-MAT-22: 4 % of the products, thousands of chunks each, most of them a handful of entries).
+// Column by column -- multiply_kernel -- every such chunk costs a chain of dependent loads for its column (6 ms per launch for
+// 1.4 GB of records).  This kernel walks the ROW instead: the chunk table holds its chunks in staging order, a wave takes a
+// slice of the row's staging span, 64 chunks at a time (lane q: chunk q's span, B row and A value), and its lanes walk the
+// products -- consecutive lanes write consecutive records: full lines, streamed.  Same products, same places (cscMulcsr,
+// SimSpGEMM.cpp:265-281).
+constexpr int kExpandThreads = 256;
+constexpr uint32_t kExpandJob = 8192;   // products per workgroup
+// jobs of long row h: those the multiply stages plainly (mode `split`, or `stretch` unless the panel's stretch rows are hub rows)
+struct ExpandJobs {
+    const uint32_t *rows; const uint64_t *row_off; const uint8_t *hmode; uint8_t mode_a, mode_b;
+    __device__ uint64_t operator()(uint64_t h) const {
+        const uint8_t m = hmode[h];
+        if (m != mode_a && m != mode_b) return 0ull;
+        const uint64_t U = row_off[rows[h] + 1] - row_off[rows[h]];
+        return (U + kExpandJob - 1) / kExpandJob;
+    }
+};
+template <class T>
+__global__ __launch_bounds__(kExpandThreads) void expand_rows_kernel(
+    const uint32_t *__restrict__ rows, uint32_t nlong, const uint64_t *__restrict__ jobbase, const uint64_t *__restrict__ row_off, uint64_t base,
+    const uint32_t *__restrict__ rowfirst, const uint64_t *__restrict__ ct_off, const uint32_t *__restrict__ ct_bs, const uint32_t *__restrict__ perm,
+    const T *__restrict__ a_vals, const uint32_t *__restrict__ b_colidx, const T *__restrict__ b_vals, Part<T> *__restrict__ stage) {
+    const uint64_t job = blockIdx.x;
+    if (job >= jobbase[nlong]) return;
+    const unsigned lane = lane_id(), w = threadIdx.x >> 6;
+    const uint32_t h = (uint32_t)(upper_bound_dev(jobbase, 0, (uint64_t)nlong + 1, job) - 1);
+    const uint32_t row = rows[h];
+    const uint64_t rbeg = row_off[row], rend = row_off[row + 1];
+    constexpr uint32_t per = kExpandJob / (kExpandThreads / kWave);
+    const uint64_t p0 = rbeg + (job - jobbase[h]) * kExpandJob + (uint64_t)w * per;   // the wave's slice of the staging span
+    if (p0 >= rend) return;
+    const uint64_t p1 = min(p0 + per, rend);
+    const uint32_t c0 = rowfirst[row], c1 = rowfirst[row + 1];
+    // the chunk that holds product p0 (chunks without entries are never the answer: strictly ascending offsets decide)
+    uint32_t c = (uint32_t)(upper_bound_dev(ct_off, (uint64_t)c0, (uint64_t)c1, p0) - 1);
+    constexpr uint32_t kUnroll = 4;
+    for (; c < c1; c += kWave) {
+        const uint32_t cq = c + lane;
+        const bool cv = cq < c1;
+        const uint64_t o0 = cv ? ct_off[cq] : ~0ull, o1 = cv ? ct_off[cq + 1] : ~0ull;
+        if (wave_bcast(o0, 0u) >= p1) break;   // (wave-uniform)
+        const uint32_t bsv = cv ? ct_bs[cq] : 0u;
+        const T av = cv ? a_vals[perm[cq]] : T(0);
+        // the group's products inside the slice
+        const uint64_t g0 = max(wave_bcast(o0, 0u), p0);
+        const uint32_t nval = min((uint32_t)kWave, c1 - c);
+        const uint64_t g1 = min(wave_bcast(o1, nval - 1), p1);
+        for (uint64_t ib = g0; ib < g1; ib += kUnroll * kWave) {
+            uint32_t bc[kUnroll];
+            T bv[kUnroll], cav[kUnroll];
+#pragma unroll
+            for (uint32_t u = 0; u < kUnroll; u++) {
+                const uint64_t i = ib + u * kWave + lane;
+                uint32_t lo = 0, hi = kWave;   // last lane whose chunk starts at or before i (lanes past the end hold ~0: never)
+#pragma unroll
+                for (int step = 0; step < 6; step++) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const uint64_t sv = (uint64_t)__shfl((long long)o0, (int)mid);
+                    if (sv <= i) lo = mid; else hi = mid;
+                }
+                const uint64_t cst = (uint64_t)__shfl((long long)o0, (int)lo);
+                const uint32_t cbs = (uint32_t)__shfl((int)bsv, (int)lo);
+                cav[u] = __shfl(av, (int)lo);
+                const uint32_t b = i < g1 ? cbs + (uint32_t)(i - cst) : 0u;   // clamped, branch-free: the loads stay in flight
+                bc[u] = b_colidx[b];
+                bv[u] = b_vals[b];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kUnroll; u++) {
+                const uint64_t i = ib + u * kWave + lane;
+                if (i < g1) stream_store_part(&stage[i - base], bc[u], cav[u] * bv[u]);
+            }
+        }
     }
 }
 
@@ -772,6 +911,7 @@ struct alignas(8) MergeSmem {
         uint16_t rank[CAP + 1];
     };
     uint32_t rowo[kTileMaxRows + 1];
+    uint32_t gbits[CAP / 32];   // gathered tiles (merge_tiles_kernel): one bit per entry that starts a run; all clear between tiles
     uint32_t scratch[NT / kWave + 1];
     uint32_t nlongrun;  // runs longer than kRunShort, summed by whole waves (their positions and sums: behind `rank`)
     uint32_t hcount;  // distinct (row, col) keys of the tile, counted by hashing before the sort
@@ -967,12 +1107,105 @@ constexpr uint32_t kNoRuns = 0xffffffffu;   // vrun_off of a segment whose recor
 template <class T> struct RunDesc;
 template <> struct alignas(16) RunDesc<double> { uint32_t dst, src; double av; };
 template <> struct alignas(4) RunDesc<float> { uint32_t dst, src; float av; };
+// SHORT rows (those that fit a tile) are gathered the same way: their runs are their chunks -- the chunk table of the symbolic
+// phase as descriptors (dst: the chunk's staging offset, which stays virtual), chunks without entries left out, made once per
+// product (short_runs_kernel); a tile of rows [ra, ra + nr) takes descriptors [rowfirst0[ra], rowfirst0[ra + nr)).  With both,
+// only rows beyond the planner (hub rows, rows with a range that exceeds a tile) are still multiplied into HBM.
 template <class T>
 struct GatherArgs {
-    const RunDesc<T> *runs = nullptr;     // the panel's run table (null: no gathered rows)
+    const RunDesc<T> *runs = nullptr;     // the panel's run table (null: no gathered long rows)
+    const RunDesc<T> *runs0 = nullptr;    // the product's short rows (null: they are staged)
     const uint32_t *b_colidx = nullptr;
     const T *b_vals = nullptr;
 };
+// flag(c) = chunk c (in (row, k) order) has entries and belongs to a row of at most `cap` partial products
+struct ShortRunFlag {
+    const uint64_t *off; const uint32_t *rows_sorted; const uint64_t *row_off; uint64_t cap;
+    __device__ uint32_t operator()(uint64_t c) const {
+        const uint32_t r = rows_sorted[c];
+        return (off[c + 1] > off[c] && row_off[r + 1] - row_off[r] <= cap) ? 1u : 0u;
+    }
+};
+template <class T>
+__global__ void short_runs_kernel(ShortRunFlag f, const uint32_t *cidx, uint64_t nnz, const uint32_t *bs, const uint32_t *perm, const T *a_vals,
+                                  RunDesc<T> *runs0) {
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nnz || !f(c)) return;
+    RunDesc<T> rd;
+    rd.dst = (uint32_t)f.off[c];
+    rd.src = bs[c];
+    rd.av = a_vals[perm[c]];
+    runs0[cidx[c]] = rd;
+}
+__global__ void short_rowfirst_kernel(const uint32_t *rowfirst, const uint32_t *cidx, uint64_t M, uint32_t *rowfirst0) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= M) rowfirst0[i] = cidx[rowfirst[i]];
+}
+// A gathered row may have a range that exceeds a tile (the hub columns: one column fed by more chunks than a tile holds
+// entries).  Such a segment goes to the paths for over-long segments -- dense accumulators, big in-place tiles, the global sort
+// -- which read RECORDS: this kernel writes the segment's records where they would have been written (its place in the second
+// buffer), from its run descriptors; everything else of the row stays virtual.  One workgroup per segment, a wave per slice.
+template <class T>
+__global__ __launch_bounds__(kExpandThreads) void expand_segments_kernel(
+    const uint32_t *__restrict__ seglist, uint32_t nseg, const uint64_t *__restrict__ vrow_off, const uint32_t *__restrict__ vrun_off,
+    const uint32_t *__restrict__ vrun_end, const RunDesc<T> *__restrict__ runs, const uint32_t *__restrict__ b_colidx, const T *__restrict__ b_vals,
+    Part<T> *__restrict__ qstage) {
+    if (blockIdx.x >= nseg) return;
+    const uint32_t v = seglist[blockIdx.x];
+    const uint32_t r0 = vrun_off[v];
+    if (r0 == kNoRuns) return;   // not a gathered row: its records are there
+    const uint32_t R = vrun_end[v] - r0;
+    const uint64_t s = vrow_off[v], n = vrow_off[v + 1] - s;
+    const uint32_t s32 = (uint32_t)s;   // (run positions are 32 bits wide, modulo)
+    const unsigned lane = lane_id(), w = threadIdx.x >> 6;
+    constexpr uint32_t per = 2048, NW = kExpandThreads / kWave, kUnroll = 4;
+    const RunDesc<T> *__restrict__ rd = runs + r0;
+    for (uint64_t p0 = (uint64_t)w * per; p0 < n; p0 += (uint64_t)NW * per) {
+        const uint64_t p1 = min(p0 + per, n);
+        // last run that starts at or before p0
+        uint32_t lo = 0, hi = R;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)(rd[mid].dst - s32) <= p0) lo = mid; else hi = mid; }
+        for (uint32_t c = lo; c < R; c += kWave) {
+            const uint32_t cq = c + lane;
+            const bool cv = cq < R;
+            const RunDesc<T> d = rd[cv ? cq : c];
+            const uint64_t o0 = cv ? (uint64_t)(d.dst - s32) : ~0ull;
+            if (wave_bcast(o0, 0u) >= p1) break;   // (wave-uniform)
+            const uint32_t nval = min((uint32_t)kWave, R - c);
+            // where the group ends: the start of the run behind it, or the segment's end
+            uint64_t gend = n;
+            if (c + nval < R) gend = (uint64_t)(rd[c + nval].dst - s32);
+            const uint64_t g0 = max(wave_bcast(o0, 0u), p0), g1 = min(gend, p1);
+            for (uint64_t ib = g0; ib < g1; ib += kUnroll * kWave) {
+                uint32_t bc[kUnroll];
+                T bv[kUnroll], cav[kUnroll];
+#pragma unroll
+                for (uint32_t u = 0; u < kUnroll; u++) {
+                    const uint64_t i = ib + u * kWave + lane;
+                    uint32_t llo = 0, lhi = kWave;   // last lane whose run starts at or before i
+#pragma unroll
+                    for (int step = 0; step < 6; step++) {
+                        const uint32_t mid = (llo + lhi) >> 1;
+                        const uint64_t sv = (uint64_t)__shfl((long long)o0, (int)mid);
+                        if (sv <= i) llo = mid; else lhi = mid;
+                    }
+                    const uint64_t cst = (uint64_t)__shfl((long long)o0, (int)llo);
+                    const uint32_t cbs = (uint32_t)__shfl((int)d.src, (int)llo);
+                    cav[u] = __shfl(d.av, (int)llo);
+                    const uint32_t b = i < g1 ? cbs + (uint32_t)(i - cst) : 0u;   // clamped, branch-free
+                    bc[u] = b_colidx[b];
+                    bv[u] = b_vals[b];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kUnroll; u++) {
+                    const uint64_t i = ib + u * kWave + lane;
+                    if (i < g1) qstage[s + i] = Part<T>{bc[u], cav[u] * bv[u]};
+                }
+            }
+        }
+    }
+}
+
 // Everything merge_tiles_kernel needs per level.
 template <class T>
 struct MergeLevels {
@@ -988,7 +1221,7 @@ template <int CAP>
 __global__ void tile_desc_kernel(const uint32_t *tile_rows, uint32_t ntiles, uint64_t r_end, const uint64_t *row_off,
                                  uint64_t base, uint32_t lvl, const uint32_t *j0, const uint32_t *extra, uint32_t nlong,
                                  const uint32_t *tb, const uint32_t *vcol0, const uint32_t *vcol1, TileDesc *desc,
-                                 const uint32_t *vrun_off = nullptr, const uint32_t *vrun_end = nullptr) {
+                                 const uint32_t *vrun_off = nullptr, const uint32_t *vrun_end = nullptr, const uint32_t *rowfirst0 = nullptr) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
     const uint64_t ra = tile_rows[t], rb = (t + 1 < ntiles) ? (uint64_t)tile_rows[t + 1] : r_end;
@@ -1002,6 +1235,10 @@ __global__ void tile_desc_kernel(const uint32_t *tile_rows, uint32_t ntiles, uin
     d.kbits = 0;
     d.rbeg = 0;
     d.rcnt = 0;
+    if (lvl == 0 && rowfirst0 && d.n <= (uint32_t)CAP) {   // short rows, gathered: their chunks are their runs
+        d.rbeg = rowfirst0[ra];
+        d.rcnt = rowfirst0[rb] - d.rbeg;
+    }
     uint32_t pos = t;
     if (nlong) {
         if (lvl == 0) {
@@ -1132,6 +1369,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
     static_assert(kTileMaxRows + 1 <= NT, "row offsets are fetched one per thread");
     unsigned tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     uint32_t shard = 0;   // (thread 0's copy is the one in use: it takes every ticket of the workgroup)
+    if constexpr (GA) { if (tid < (uint32_t)kTileCap / 32u) sm.gbits[tid] = 0; }   // (the barrier below)
     if (tid == 0) {
         if (nshards > 1) shard = atomicAdd(&ticket[nshards * kTicketStride], 1u) % nshards;   // by arrival, see take_ticket
         const uint32_t t0 = (ABL & 4) ? blockIdx.x : take_ticket(ticket, nshards, shard, ntiles);
@@ -1179,7 +1417,8 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                                            // `tid` (dst, src) waits where a staged tile's first record would (the rest, if any, is
                                            // loaded when the tile starts)
                 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                const u32x2 ds2 = *reinterpret_cast<const u32x2 *>(&ga.runs[tid < dd.rcnt ? dd.rbeg + tid : dd.rbeg]);
+                const RunDesc<T> *__restrict__ gruns = dd.lvl ? ga.runs : ga.runs0;
+                const u32x2 ds2 = *reinterpret_cast<const u32x2 *>(&gruns[tid < dd.rcnt ? dd.rbeg + tid : dd.rbeg]);
                 lrec[0].w[0] = ds2.x;
                 lrec[0].w[1] = ds2.y;
                 return;
@@ -1258,50 +1497,45 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
         // sort in `pad` (idle until the values arrive; f32 tiles have none and keep the registers)
         uint32_t rq[(LPT + 1) / 2];
         constexpr bool kRunInPad = GA && Smem::kWide;
+        // ... and (f64 tiles: the kernel has the registers) the entries' positions in B, so that after the sort B's value and
+        // the run's A value are fetched side by side instead of one after the other
+        constexpr bool kKeepPos = GA && Smem::kWide;
+        uint32_t bpos[LPT];
+        // ---- a gathered tile: its records are formed here (cscMulcsr for these rows) ----
+        // Its runs go to LDS first: position in B minus the run's start inside the tile (gsrc: where the hash table's first words
+        // would be -- the table of such a tile is what lies behind), and one BIT per run start (sm.gbits: all clear between
+        // tiles).  Entry i belongs to the last run that starts at or before i = (run starts up to i) - 1: a wave owns a
+        // contiguous span of the tile, so that is a running count plus a population count inside the 64 bits of the wave's
+        // current window -- no search.  The entry's column is fetched now, its value after the sort (the sort needs the keys
+        // only, and a thread cannot hold six values through it).
+        constexpr uint32_t GW = GA ? (uint32_t)kTileCap : 0u;   // words of gsrc
+        constexpr uint32_t HSG = HS - GW;                       // words of a gathered tile's hash table
+        uint32_t *gsrc = htab, *htab_g = htab + GW;
         if constexpr (GA) {
             if (gath) {
-                // ---- a gathered tile: its records are formed here (cscMulcsr for these rows) ----
-                // The tile's runs -> LDS (everything behind key0 is idle until the hash count): start inside the tile and position
-                // in B minus that start.  Entry i belongs to the last run that starts at or before i; its column is fetched now, its
-                // value after the sort (the sort needs the keys only, and a thread cannot hold six values through it).
-                static_assert(sizeof(sm.pos0) + sizeof(sm.pad) + sizeof(sm.key1) + sizeof(sm.pos1) + sizeof(sm.cnt) >= (size_t)kTileCap * (4 + 2),
-                              "gathered tiles: the run table fits behind key0");
-                uint32_t *gsrc = reinterpret_cast<uint32_t *>(sm.pos0);
-                uint16_t *gst = reinterpret_cast<uint16_t *>(gsrc + kTileCap);
-                const uint32_t R = d.rcnt, tile0 = (uint32_t)(s + base);   // (the second buffer's positions are 32 bits wide, modulo)
+                static_assert(HS > 2 * GW, "gathered tiles: the run table leaves a hash table of more than two words per entry... of half the entries");
+                const uint32_t R = d.rcnt, tile0 = (uint32_t)(s + base);   // (the buffers' positions are 32 bits wide, modulo)
+                const RunDesc<T> *__restrict__ gruns = d.lvl ? ga.runs : ga.runs0;
                 for (uint32_t x = tid; x < R; x += NT) {
                     uint32_t dst = lrec[0].w[0], src = lrec[0].w[1];
-                    if (x != tid) { const RunDesc<T> rd = ga.runs[d.rbeg + x]; dst = rd.dst; src = rd.src; }
+                    if (x != tid) { const RunDesc<T> rd = gruns[d.rbeg + x]; dst = rd.dst; src = rd.src; }
                     const uint32_t st = dst - tile0;
                     gsrc[x] = src - st;
-                    gst[x] = (uint16_t)st;
+                    atomicOr(&sm.gbits[st >> 5], 1u << (st & 31u));
                 }
-                if (tid <= nr) sm.rowo[tid] = (uint32_t)(ro - base - s);
-                __syncthreads();
-                uint32_t bpos[LPT];
-#pragma unroll
-                for (int q = 0; q < (LPT + 1) / 2; q++) rq[q] = 0;
-#pragma unroll
-                for (int q = 0; q < LPT; q++) {
-                    const uint32_t i = ix0 + q * ixs;
-                    uint32_t lo = 0, hi = R;   // last run with gst <= i (gst[0] = 0)
-                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)gst[mid] <= i) lo = mid; else hi = mid; }
-                    bpos[q] = i < n ? gsrc[lo] + i : 0u;   // clamped: the loads below go out together
-                    rq[q >> 1] |= (i < n ? lo : 0u) << (16 * (q & 1));
+                if (early) {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    static_assert((offsetof(Smem, pos0) + 4u * GW) % 16 == 0, "gathered tiles: the hash table starts 16-byte aligned");
+                    constexpr uint32_t nvec = HSG / 4, tail = HSG % 4;
+                    u32x4 *hv = reinterpret_cast<u32x4 *>(htab_g);
+                    const u32x4 ones = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+                    for (uint32_t i = tid; i < nvec; i += NT) hv[i] = ones;
+                    if (tid < tail) htab_g[nvec * 4 + tid] = 0xffffffffu;
+                    if (tid == 0) sm.hcount = 0;
                 }
-                uint32_t bc[LPT];
-#pragma unroll
-                for (int q = 0; q < LPT; q++) bc[q] = ga.b_colidx[bpos[q]];
-#pragma unroll
-                for (int q = 0; q < LPT; q++) {
-                    const uint32_t i = ix0 + q * ixs;
-                    kq[q] = bc[q] - cbase;
-                    if (i < n) sm.key0[i] = kq[q];
-                }
-                __syncthreads();   // the run table has been read: the hash table may take its place
             }
         }
-        if (early) {
+        if (!gath && early) {
             if constexpr (ABL & 256) {
                 for (uint32_t i = tid; i < HS; i += NT) htab[i] = 0xffffffffu;
             } else {
@@ -1319,14 +1553,79 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
             }
             if (tid == 0) sm.hcount = 0;
         }
-        if (!gath && tid <= nr) sm.rowo[tid] = (uint32_t)(ro - base - s);
+        if (tid <= nr) sm.rowo[tid] = (uint32_t)(ro - base - s);
         __syncthreads();
         OSP_PROF_MARK(0);
         // stage the keys: (local row << colbits) | col, or col - cbase.  The payload (staging position) is implicit
         // until pass 0; the values stay in registers until the sort is over.
         uint32_t fresh = 0;
         const bool rw_tile = ROWWISE && d.lvl == 0;
-        if (rw_tile) {
+        if constexpr (GA) {
+            if (gath) {
+                // run starts before the wave's span (wave-uniform), then window by window
+                uint32_t cnt0 = 0;
+                {
+                    const uint32_t nwords = w * (kSpan / 32u);   // <= 3 * 14 words: one per lane
+                    static_assert((NW - 1) * (kSpan / 32u) <= (uint32_t)kWave, "gathered tiles: the bits before a wave's span, one word per lane");
+                    cnt0 = wave_reduce_sum<uint32_t>(lane < nwords ? (uint32_t)__popc(sm.gbits[lane]) : 0u);
+                    cnt0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt0);
+                }
+#pragma unroll
+                for (int q = 0; q < (LPT + 1) / 2; q++) rq[q] = 0;
+#pragma unroll
+                for (int q = 0; q < LPT; q++) {
+                    const uint32_t i = ix0 + q * ixs;
+                    const uint32_t wi = w * (kSpan / 32u) + 2u * (uint32_t)q;   // the window's two words (wave-uniform address)
+                    const uint32_t mlo = sm.gbits[wi], mhi = sm.gbits[wi + 1];
+                    // starts at or before my position inside the window: those below my lane, and mine
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+                    const uint32_t own = ((lane < 32 ? mlo >> lane : mhi >> (lane - 32)) & 1u);
+                    const uint32_t r = cnt0 + below + own - 1u;
+                    cnt0 += (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
+                    bpos[q] = i < n ? gsrc[r] + i : 0u;   // clamped: the loads below go out together
+                    rq[q >> 1] |= (i < n ? r : 0u) << (16 * (q & 1));
+                }
+                uint32_t bc[LPT];
+#pragma unroll
+                for (int q = 0; q < LPT; q++) bc[q] = ga.b_colidx[bpos[q]];
+#pragma unroll
+                for (int q = 0; q < LPT; q++) {
+                    const uint32_t i = ix0 + q * ixs;
+                    if (relkey) {
+                        kq[q] = bc[q] - cbase;
+                    } else {   // short rows: the entry's row inside the tile is the key's major part
+                        uint32_t lo = 0, hi = nr;  // last r with rowo[r] <= i
+                        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sm.rowo[mid] <= i) lo = mid; else hi = mid; }
+                        kq[q] = (colbits < 32 ? (lo << colbits) : 0u) | bc[q];
+                    }
+                    if (i < n) sm.key0[i] = kq[q];
+                }
+                OSP_PROF_MARK(11);   // gathered tile: run lookup, columns from B
+                if (early) {
+                    uint32_t hq[LPT], oq[LPT];
+#pragma unroll
+                    for (int q = 0; q < LPT; q++) {
+                        hq[q] = (uint32_t)(((uint64_t)(kq[q] * 2654435761u) * HSG) >> 32);
+                        oq[q] = kq[q];
+                        if (ix0 + q * ixs < n) oq[q] = atomicCAS(&htab_g[hq[q]], 0xffffffffu, kq[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < LPT; q++) {
+                        if (ix0 + q * ixs < n) {
+                            uint32_t old = oq[q], h = hq[q];
+                            while (old != 0xffffffffu && old != kq[q]) {
+                                h = (h + 1 == HSG) ? 0u : h + 1;
+                                old = atomicCAS(&htab_g[h], 0xffffffffu, kq[q]);
+                            }
+                            fresh += old == 0xffffffffu;
+                        }
+                    }
+                }
+            }
+        }
+        if (gath) {
+            // (formed above)
+        } else if (rw_tile) {
             if constexpr (ROWWISE) {
                 // Row-wise tile: the partial products of rows [ra, ra+nr) are formed here.  The rows' chunks (one per
                 // non-zero A[i,k], in (row, k) order -- the staging order) are taken kRwGroup at a time by a wave: lane q
@@ -1396,7 +1695,6 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                 }
             }
         } else {
-            if (!gath) {
 #pragma unroll
             for (int q = 0; q < LPT; q++) {
                 const uint32_t i = ix0 + q * ixs;
@@ -1411,7 +1709,6 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                     }
                     sm.key0[i] = kq[q];
                 }
-            }
             }
             if (early) {
                 // first probes of all the thread's keys go out together; only collisions with a different key walk on
@@ -1444,12 +1741,15 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
         const uint32_t wbeg = min(w * per, n), wend = min(wbeg + per, n);
         int cur = 0;
         __syncthreads();   // keys staged, hash count complete
-        if constexpr (kRunInPad) {
+        if constexpr (GA) {
             if (gath) {
+                if (tid < (uint32_t)kTileCap / 32u) sm.gbits[tid] = 0;   // (every thread has read them: the barrier above)
+                if constexpr (kRunInPad) {
 #pragma unroll
-                for (int q = 0; q < LPT; q++) {
-                    const uint32_t i = ix0 + q * ixs;
-                    if (i < n) sm.pad[i] = (uint16_t)(rq[q >> 1] >> (16 * (q & 1)));
+                    for (int q = 0; q < LPT; q++) {
+                        const uint32_t i = ix0 + q * ixs;
+                        if (i < n) sm.pad[i] = (uint16_t)(rq[q >> 1] >> (16 * (q & 1)));
+                    }
                 }
             }
         }
@@ -1609,6 +1909,20 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                 // the values of a gathered tile: the entry's run (its descriptor comes from L2) -> its place in B -> A value x B value,
                 // the product cscMulcsr forms (one rounding, as in multiply_kernel)
                 const uint32_t tile0 = (uint32_t)(s + base);
+                const RunDesc<T> *__restrict__ gruns = d.lvl ? ga.runs : ga.runs0;
+                T bv[LPT];
+                if constexpr (kKeepPos) {
+                    T av[LPT];
+#pragma unroll
+                    for (int q = 0; q < LPT; q++) {
+                        const uint32_t i = ix0 + q * ixs;
+                        bv[q] = ga.b_vals[bpos[q]];
+                        av[q] = gruns[d.rbeg + (i < n ? (uint32_t)sm.pad[i] : 0u)].av;
+                    }
+#pragma unroll
+                    for (int q = 0; q < LPT; q++) vq[q] = av[q] * bv[q];
+                    (void)tile0;
+                } else {
                 RunDesc<T> rdq[LPT];
 #pragma unroll
                 for (int q = 0; q < LPT; q++) {
@@ -1616,9 +1930,8 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                     uint32_t r;
                     if constexpr (kRunInPad) r = i < n ? (uint32_t)sm.pad[i] : 0u;
                     else r = (rq[q >> 1] >> (16 * (q & 1))) & 0xffffu;
-                    rdq[q] = ga.runs[d.rbeg + r];
+                    rdq[q] = gruns[d.rbeg + r];
                 }
-                T bv[LPT];
 #pragma unroll
                 for (int q = 0; q < LPT; q++) {
                     const uint32_t i = ix0 + q * ixs;
@@ -1626,6 +1939,7 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                 }
 #pragma unroll
                 for (int q = 0; q < LPT; q++) vq[q] = rdq[q].av * bv[q];
+                }
             }
         }
         if (npass == 0) __syncthreads();

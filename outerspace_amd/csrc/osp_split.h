@@ -671,6 +671,8 @@ struct GatherPlan {
     const uint64_t *rdbase = nullptr;   // first descriptor of every long row's block in the run table (null: no row is gathered)
     uint32_t *vrun_off = nullptr, *vrun_end = nullptr;   // per segment (virtual row): its descriptors
     uint32_t *rowruns = nullptr;
+    uint32_t *nwritten = nullptr;       // += 1 per direct row that is NOT gathered: rows the multiply writes through cells
+    uint32_t over = 1;                  // rows with a range that exceeds a tile are gathered too
 };
 // gstat[0..2] += gathered rows, their partial products, their runs (few workgroups: they end in atomics on three hot words --
 // one set per ROW inside the planner made it twice as slow)
@@ -812,7 +814,9 @@ __global__ __launch_bounds__(kDirectThreads, 8) void direct_plan_kernel(
     }
     __syncthreads();
     const uint32_t T = s_T;   // <= Ta - 1 (split_params_kernel's bound)
-    const bool gathered = gp.rdbase != nullptr && s_over == 0;   // (workgroup-uniform)
+    // (a range that exceeds a tile -- s_over -- is gathered like the others: expand_segments_kernel writes its records before the
+    // paths for over-long segments read them; OSP_GATHER_OVER=0, a debugging aid, leaves such rows to the multiply as round 4 did)
+    const bool gathered = gp.rdbase != nullptr && (s_over == 0 || gp.over);   // (workgroup-uniform)
     for (uint32_t d = tid; d < nfine; d += NT) {   // the range of every bin: last t with rbin0[t] <= d
         uint32_t lo = 0, hi = T;
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (rbin0[mid] <= d) lo = mid; else hi = mid; }
@@ -836,7 +840,11 @@ __global__ __launch_bounds__(kDirectThreads, 8) void direct_plan_kernel(
         uint32_t *nzc = reinterpret_cast<uint32_t *>(nxt), *ncur = rbin0;   // runs of every range (then: their exclusive prefix); runs written so far
         static_assert(sizeof(nxt) >= (kDirectMaxRanges + 1) * sizeof(uint32_t), "runs per range: where the grouping's chain was");
         const uint32_t rowbase = (uint32_t)gp.rdbase[h];
-        for (uint32_t t = tid; t <= T; t += NT) { nzc[t] = 0; ncur[t] = 0; }
+        // first column of every range (phase A's bisections; `cursor` is idle until phase B)
+        static_assert(kDirectMaxRanges + 1 <= NT, "one range per thread");
+        const uint32_t bcol_t = tid <= T ? (uint32_t)min((uint64_t)rbin0[tid] << sh, (uint64_t)0xffffffffu) : 0u;
+        __syncthreads();
+        if (tid <= T) { nzc[tid] = 0; ncur[tid] = 0; if (tid < T) cursor[tid] = bcol_t; }
         // (the A values of a row of ONE block of chunks are fetched now -- two dependent loads -- and arrive during the walk)
         if (!multi) { for (uint32_t cl = tid; cl < nc; cl += NT) avs[cl] = a_vals[perm[c0 + cl]]; }
         __syncthreads();
@@ -849,11 +857,31 @@ __global__ __launch_bounds__(kDirectThreads, 8) void direct_plan_kernel(
             else __syncthreads();
             have_cb = cb; have_nb = nb; have_E = E;
             OSP_PLAN_MARK(1);
-            for_entries(nb, E, [&](uint32_t cl, uint32_t col, bool valid) {
-                const uint32_t key = valid ? __umul24(cl, T) + (uint32_t)lut[col >> sh] : 0xffffffffu;
-                uint32_t runlen;
-                if (wave_run_head(key, valid, runlen, above)) atomicAdd(&cellm[key], runlen);
-            });
+            // The block's (chunk, range) counts.  B's rows are sorted: a chunk's entries below a range's first column are a lower
+            // bound, ~log2(length) dependent loads per (chunk, boundary) instead of a walk over every entry -- an eightieth of
+            // the walk's instructions for a typical row (28 chunks of 177 entries, 3 ranges; the planner is bound by its vector
+            // instructions), more than the walk only where the chunks are shorter than 8 entries per boundary: those walk.
+            if (T > 1 && (uint64_t)E >= (uint64_t)nb * (T - 1) * 8u) {
+                for (uint32_t x = tid; x < nb * (T - 1); x += NT) {
+                    const uint32_t cl = x / (T - 1), t = x - cl * (T - 1) + 1;
+                    const uint32_t col = cursor[t], b0 = cbs[cl] + cst[cl];
+                    uint32_t lo = 0, hi = cst[cl + 1] - cst[cl];
+                    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (b_colidx[b0 + mid] < col) lo = mid + 1; else hi = mid; }
+                    lsm[cl * T + t] = lo;
+                }
+                for (uint32_t cl = tid; cl < nb; cl += NT) lsm[cl * T] = 0;
+                __syncthreads();
+                for (uint32_t x = tid; x < nb * T; x += NT) {
+                    const uint32_t cl = x / T, t = x - cl * T;
+                    cellm[x] = (t + 1 < T ? lsm[x + 1] : cst[cl + 1] - cst[cl]) - lsm[x];
+                }
+            } else {
+                for_entries(nb, E, [&](uint32_t cl, uint32_t col, bool valid) {
+                    const uint32_t key = valid ? __umul24(cl, T) + (uint32_t)lut[col >> sh] : 0xffffffffu;
+                    uint32_t runlen;
+                    if (wave_run_head(key, valid, runlen, above)) atomicAdd(&cellm[key], runlen);
+                });
+            }
             __syncthreads();
             OSP_PLAN_MARK(4);
             for (uint32_t x = tid; x < nb * T; x += NT) {
@@ -872,6 +900,7 @@ __global__ __launch_bounds__(kDirectThreads, 8) void direct_plan_kernel(
                 nzc[T] = total;
                 gp.rowruns[h] = total;
             }
+            if (tid < T) cursor[tid] = 0;   // (the ranges' first columns have been used)
         }
         __syncthreads();
         for (uint32_t t = tid; t < Ta; t += NT) {
@@ -901,16 +930,17 @@ __global__ __launch_bounds__(kDirectThreads, 8) void direct_plan_kernel(
                 uint32_t run0 = 0, nrun0 = 0;
                 __syncthreads();
                 if (on) {
-                    uint32_t sum = 0, nz = 0;   // (a range holds at most `cap` products, a block at most CBL chunks: 16 bits each)
+                    uint32_t sum = 0, nz = 0;   // (a row holds at most 2^20 products -- kDirectDenseMax --, a block at most CBL chunks: 21 + 11 bits)
+                    static_assert(kDirectDenseMax <= (1ull << 20) && CBL < 2048, "products and runs of a group of chunks in one word");
                     for (uint32_t cl = g * S; cl < min(nb, (g + 1) * S); cl++) { const uint32_t c = cellm[cl * T + t]; sum += c; nz += c != 0; }
-                    psum[tid] = sum | (nz << 16);
+                    psum[tid] = sum | (nz << 21);
                     run0 = cursor[t];
                     nrun0 = ncur[t];
                 }
                 __syncthreads();
                 if (on) {
                     uint32_t run = run0, nrun = nrun0;
-                    for (uint32_t gg = 0; gg < g; gg++) { const uint32_t p = psum[gg * Tb + (t - t0)]; run += p & 0xffffu; nrun += p >> 16; }
+                    for (uint32_t gg = 0; gg < g; gg++) { const uint32_t p = psum[gg * Tb + (t - t0)]; run += p & 0x1fffffu; nrun += p >> 21; }
                     const uint32_t rbase = q0 + roff[t];
                     RunDesc<V> *__restrict__ out = runs + rowbase + nzc[t];
                     for (uint32_t cl = g * S; cl < min(nb, (g + 1) * S); cl++) {
@@ -934,6 +964,7 @@ __global__ __launch_bounds__(kDirectThreads, 8) void direct_plan_kernel(
         return;
     }
     for (uint32_t d = tid; d < lutw * 4; d += NT) reinterpret_cast<uint8_t *>(rb)[d] = d < nfine ? lut[d] : (uint8_t)0;
+    if (tid == 0 && gp.rdbase != nullptr && gp.nwritten) atomicAdd(gp.nwritten, 1u);   // (rare: the panel's other direct rows are gathered)
     OSP_PLAN_MARK(3);   // grouping, segment tables
     // ---- 3. cells, a block of chunks at a time
     const uint32_t CB = max(1u, min((uint32_t)CBL, (uint32_t)kCellsLds / T));
