@@ -49,9 +49,17 @@ struct Context {
     void need_aux() {
         if (aux) return;
         if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess) { aux = nullptr; throw Error(OSP_ERR_HIP, "hipStreamCreate failed"); }
-        if (hipEventCreateWithFlags(&aux_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&aux_join, hipEventDisableTiming) != hipSuccess)
+        if (hipEventCreateWithFlags(&aux_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&aux_join, hipEventDisableTiming) != hipSuccess) {
+            drop_aux();   // (never a stream without its events: the next product would skip the creation)
             throw Error(OSP_ERR_HIP, "hipEventCreate failed");
+        }
     }
+    // The pool is not stream-aware: a released block goes to whoever asks next.  While the plan of the next panel runs on the
+    // second stream that is safe only as long as NOTHING is released between the fork event and the plan's own allocations
+    // (a block the multiply still reads would go straight to a plan kernel).  The window is marked and every release inside
+    // it counted: merge_pipeline turns a non-zero count into an error instead of a silent corruption.
+    bool fork_window = false;
+    uint64_t releases_in_fork_window = 0;
     void drop_aux() {
         if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); aux = nullptr; }
         if (aux_fork) { (void)hipEventDestroy(aux_fork); aux_fork = nullptr; }
@@ -206,6 +214,7 @@ struct Context {
     }
     void release(void *p) {
         if (!p) return;
+        if (fork_window) releases_in_fork_window++;
         if (fence_mode()) return;  // leaked on purpose, see fence_mode()
         if (guard_mode()) { release_guarded(p); return; }
         auto it = live.find(p);
@@ -1305,7 +1314,8 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         const uint64_t count = (npanels == 1) ? P : h_off[r1] - base;
         if (plan.p0.nlong) plan.qstage = plan.sc.template get<Part<T>>(plan.nh);   // (not before: the plan may be a panel ahead)
         const bool beside = overlap && p + 1 < npanels;
-        if (beside) OSP_HIP(hipEventRecord(ctx->aux_fork, s));
+        if (beside) { OSP_HIP(hipEventRecord(ctx->aux_fork, s)); ctx->fork_window = true; ctx->releases_in_fork_window = 0; }
+        struct WindowEnd { Context *c; ~WindowEnd() { c->fork_window = false; } } window_end{ctx};
         tm.begin(PH_MUL);
         bool column_major = count != 0, desc_only = false;
         if (count && plan.xjobbase && plan.xjobs_bound) {
@@ -1327,6 +1337,10 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
                                        plan.ga.runs != nullptr, plan.p0.nlong != 0, desc_only);
         tm.end(PH_MUL);
         if (beside) {
+            ctx->fork_window = false;
+            if (ctx->releases_in_fork_window)
+                throw Error(OSP_ERR_HIP, "internal: " + std::to_string(ctx->releases_in_fork_window) + " pooled buffers were released between the fork of the "
+                                         "second stream and the next panel's plan (the pool is not stream-aware: see Context::fork_window)");
             nxt = plan_one(p + 1, true);
             OSP_HIP(hipStreamWaitEvent(s, ctx->aux_join, 0));
         }

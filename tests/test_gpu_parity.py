@@ -648,11 +648,13 @@ def test_lattice_shape_vs_oracle(ctx, port, tname):
 
 def test_stream_copy_probe(_ctx_shared):
     """osp_stream_copy_probe (bench.py's roofline.peak_measured): a plain copy on the context's stream, read + written bytes per
-    second.  Anything an MI355X does is far above 1 TB/s and cannot exceed the data sheet's 8; bad arguments are refused."""
+    second, on buffers far beyond the last-level cache (2 GiB each).  The number is a measurement, not a constant of one SKU:
+    it must be positive, finite and not absurdly small; bad arguments are refused."""
     import ctypes as C
+    import math
     from outerspace_amd import _lib
-    g = _ctx_shared.stream_copy_gbps(256 << 20, 5)
-    assert 1000.0 < g < 8000.0, g
+    g = _ctx_shared.stream_copy_gbps(2 << 30, 3)
+    assert math.isfinite(g) and g > 100.0, g
     out = C.c_double()
     assert _lib.lib().osp_stream_copy_probe(_ctx_shared._h, 16, 1, C.byref(out)) == _lib.ERR_ARG
     assert _lib.lib().osp_stream_copy_probe(_ctx_shared._h, 1 << 20, 0, C.byref(out)) == _lib.ERR_ARG
@@ -689,7 +691,10 @@ def test_rmat22_full_size_properties_and_slab_parity(ctx, port):
         columns strictly ascending inside every row, row sums C*1 = A*(B*1), total 1^T C 1 = (1^T A)(B 1);
       * linearity: the product of (2A) and B, streamed panel by panel, is exactly 2C with the same structure;
       * parity proper on two k-slabs (the unit a k-shard computes), bit for bit against the oracle: the hub column k = 0
-        alone (9.9e7 partial products, no duplicates) and 77 k columns from the middle of the range (5e7 partial products)."""
+        alone (9.9e7 partial products, no duplicates) and 77 k columns from the middle of the range (5e7 partial products);
+      * parity proper on a ROW slab of the WHOLE product -- rows [0, r1) with 5e7 partial products over all k, the hub row and
+        planned long rows among them -- bit for bit against the oracle (entry counts per row, columns, values), and the
+        column sums of the whole result against B^T (A^T 1)."""
     import sys
     import time
     import torch
@@ -764,6 +769,40 @@ def test_rmat22_full_size_properties_and_slab_parity(ctx, port):
     assert torch.allclose(got_rowsum, want_rowsum, rtol=1e-9, atol=0)
     assert abs(float(got_rowsum.sum()) - float(want_rowsum.sum())) <= 1e-9 * float(want_rowsum.sum())
     del got_rowsum, want_rowsum, b1
+    # ---- column sums: C^T 1 = B^T (A^T 1) (a value moved to another column of its row keeps every row sum) ----
+    a1 = torch.segment_reduce(csc[2], "sum", lengths=csc[0][1:] - csc[0][:-1], unsafe=True)                  # A^T * 1, per k
+    want_colsum = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(
+        0, csr[1].long(), csr[2] * torch.repeat_interleave(a1, csr[0][1:] - csr[0][:-1]))
+    got_colsum = torch.zeros(n, dtype=torch.float64, device=dev)
+    for s0 in range(0, nnz, CH):
+        s1 = min(s0 + CH, nnz)
+        got_colsum.index_add_(0, colidx[s0:s1].long(), vals[s0:s1])
+    assert torch.allclose(got_colsum, want_colsum, rtol=1e-9, atol=0)
+    del got_colsum, want_colsum, a1
+    note("column sums compared")
+    # ---- parity proper on a ROW slab of the whole product (all k, some rows): the long-row merge at full size, bit for bit.
+    # Rows [0, r1) holding about 5e7 partial products: in R-MAT the heaviest rows come first -- the hub row (beyond the
+    # planner), rows of tens of ranges and rows of two.  The oracle multiplies A restricted to those rows. ----
+    kcol = torch.repeat_interleave(torch.arange(n, device=dev), csc[0][1:] - csc[0][:-1])                    # column of every entry of A
+    U = torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, csc[1].long(), (csr[0][1:] - csr[0][:-1])[kcol])
+    r1 = int(torch.searchsorted(torch.cumsum(U, 0), torch.tensor([50_000_000], device=dev))[0]) + 1
+    keep = csc[1].long() < r1
+    a_colptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    a_colptr[1:] = torch.cumsum(torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, kcol[keep], torch.ones_like(kcol[keep])), 0)
+    slab_p = int(U[:r1].sum())
+    kinds = (int((U[:r1] > 131072).sum()), int(((U[:r1] > 1536) & (U[:r1] <= 131072)).sum()), int((U[:r1] <= 1536).sum()))
+    note(f"row slab [0,{r1}): {slab_p} partial products ({kinds[0]} rows beyond the planner, {kinds[1]} planned long rows, {kinds[2]} short) for the oracle")
+    assert kinds[0] >= 1 and kinds[1] >= 1
+    want = port.spgemm(n, n, n, a_colptr.cpu().numpy(), csc[1][keep].cpu().numpy().view(np.uint32), csc[2][keep].cpu().numpy(),
+                       csr[0].cpu().numpy(), csr[1].cpu().numpy().view(np.uint32), csr[2].cpu().numpy())
+    note("oracle done")
+    assert want["partials"] == slab_p
+    hi = int(rowptr[r1])
+    assert torch.equal(rowptr[:r1 + 1], torch.from_numpy(want["rowptr"][:r1 + 1]).to(dev)) and hi == len(want["colidx"])   # per-row entry counts too
+    assert torch.equal(colidx[:hi], torch.from_numpy(want["colidx"].view(np.int32)).to(dev))
+    assert torch.equal(vals[:hi], torch.from_numpy(want["vals"]).to(dev))
+    del want, kcol, U, keep, a_colptr
+    note("row slab compared bit for bit")
     # ---- linearity, streamed: (2A) * B == 2 * C exactly, panel by panel against the resident result ----
     a2 = csc[2] * 2.0
     torch.cuda.synchronize()   # the library runs on its own stream

@@ -46,3 +46,37 @@ def test_products_beside_a_busy_neighbour_process(ctx, port):
     finally:
         nb.kill()
         nb.wait()
+
+
+_OVERLAP_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["OSP_TEST_ROOT"])
+from outerspace_amd import generators as gen
+from outerspace_amd import spgemm as S
+from oracle import oracle   # checker only
+port = oracle.port()
+n, rows, cols, vals = gen.rmat_coo(13, 16, "g500", seed=9)
+acsc, bcsr = S.coo_to_csc(n, rows, cols, vals), S.coo_to_csr(n, rows, cols, vals)
+want = port.spgemm(n, n, n, *acsc, *bcsr)
+with S.Context(0) as ctx:
+    for rep in range(3):
+        got = ctx.spgemm_csc_csr(n, n, n, *acsc, *bcsr, partial_capacity=150000)
+        assert got.info["panels"] > 3 and got.info["plans_overlapped"] == got.info["panels"] - 1, got.info
+        assert np.array_equal(got.rowptr, want["rowptr"]) and np.array_equal(got.colidx, want["colidx"]) and np.array_equal(got.vals, want["vals"])
+        got.close()
+print("OVERLAP_OK")
+"""
+
+
+@pytest.mark.parametrize("mode", ["OSP_POISON", "OSP_GUARD"])
+def test_plan_overlap_under_poison_and_guard(mode, port):
+    """The plan of panel p+1 runs on the context's second stream beside the multiply of panel p, and the buffer pool is not
+    stream-aware (osp_api.hip, Context::fork_window).  Products of many panels with the plans overlapped, in a process of
+    their own with every pooled buffer poisoned on allocation (OSP_POISON: a read of memory nobody wrote gives the same
+    wrong bits every time) or with guard zones around every buffer, checked when it is released (OSP_GUARD): bit-identical
+    to the oracle, and the library's own check that nothing is released inside the fork window stays silent."""
+    env = dict(os.environ, OSP_TEST_ROOT=ROOT, OSP_DIRECT_MIN_NNZ="0", OSP_PLAN_OVERLAP="1")
+    env[mode] = "1"
+    r = subprocess.run([sys.executable, "-c", _OVERLAP_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OVERLAP_OK" in r.stdout, r.stdout + r.stderr
