@@ -1691,7 +1691,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     // Small products keep the split: the plan costs a handful of launches and a read-back, which a product of a few
     // milliseconds does not earn back (web-Google shape: 2.3 ms with the split, 2.7 with direct rows).  OSP_DIRECT_MIN_NNZ
     // moves that boundary (the tests set it to 0, so that their small inputs take the direct path).
-    const uint64_t direct_min_nnz = getenv("OSP_DIRECT_MIN_NNZ") ? strtoull(getenv("OSP_DIRECT_MIN_NNZ"), nullptr, 10) : (8ull << 20);
+    const uint64_t direct_min_nnz = getenv("OSP_DIRECT_MIN_NNZ") ? strtoull(getenv("OSP_DIRECT_MIN_NNZ"), nullptr, 10) : ((getenv("OSP_GATHER") && atoi(getenv("OSP_GATHER")) == 0) ? (8ull << 20) : (2ull << 20));
     // ... unless its output rows are dense on average (at least 0.375 partial products per entry of the M x N result -- three times the
     // density from which a long row's column ranges are capped at the dense accumulators' width, plan_panel): such rows are
     // written in a few wide ranges, long runs, and summed without a sort -- 4096^2 with 880 entries per row (3.6 M non-zeros,
@@ -1754,7 +1754,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         }
         if (gather_short) {
             // the short rows' chunks as run descriptors, chunks without entries left out (once per product)
-            const ShortRunFlag sf{offs_sorted, rows_sorted, row_off, rw_cap};
+            const ShortRunFlag sf{offs_sorted};
             uint32_t *cidx = ss.get<uint32_t>(nnz + 1), *cidx_tmp = ss.get<uint32_t>(scan_scratch_entries(nnz + 1));
             device_exclusive_scan<ShortRunFlag, uint32_t>(sf, nnz, cidx, cidx_tmp, s);
             RunDesc<T> *runs0 = sc.get<RunDesc<T>>(nnz);   // (bound: every chunk; the count stays on the device)

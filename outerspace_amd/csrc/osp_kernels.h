@@ -1118,13 +1118,11 @@ struct GatherArgs {
     const uint32_t *b_colidx = nullptr;
     const T *b_vals = nullptr;
 };
-// flag(c) = chunk c (in (row, k) order) has entries and belongs to a row of at most `cap` partial products
+// flag(c) = chunk c (in (row, k) order) has entries.  (The chunks of long rows get descriptors too -- nobody reads them: telling
+// them apart costs two gathers from the row offsets per chunk, twice, and the table is allocated for every chunk anyway.)
 struct ShortRunFlag {
-    const uint64_t *off; const uint32_t *rows_sorted; const uint64_t *row_off; uint64_t cap;
-    __device__ uint32_t operator()(uint64_t c) const {
-        const uint32_t r = rows_sorted[c];
-        return (off[c + 1] > off[c] && row_off[r + 1] - row_off[r] <= cap) ? 1u : 0u;
-    }
+    const uint64_t *off;
+    __device__ uint32_t operator()(uint64_t c) const { return off[c + 1] > off[c] ? 1u : 0u; }
 };
 template <class T>
 __global__ void short_runs_kernel(ShortRunFlag f, const uint32_t *cidx, uint64_t nnz, const uint32_t *bs, const uint32_t *perm, const T *a_vals,
