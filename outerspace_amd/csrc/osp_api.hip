@@ -532,7 +532,7 @@ template <class T> struct Producer {
     //  has_long: it has rows longer than a tile)
     virtual void produce(uint64_t r0, uint64_t r1, bool whole, uint64_t base, uint64_t count,
                          Part<T> *stage, PhaseTimer &tm, const uint32_t *cells = nullptr, Part<T> *qstage = nullptr,
-                         const HubArgs *hub = nullptr, bool compact = false, bool has_long = true, bool desc_only = false) = 0;
+                         const HubArgs *hub = nullptr, bool compact = false, bool has_long = true, bool desc_only = false, bool walk_all = false) = 0;
 };
 
 // ---- rows of partial products -> merged rows -------------------------------------------------------
@@ -1333,8 +1333,11 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
             const uint32_t nw = plan.nwritten ? d2h(plan.nwritten, s) : 0u;
             column_major = plan.hub.cells != nullptr || nw != 0;
         }
+        // (the compacted multiply pays where few chunks are left to write; a panel whose hub rows hold a third of its products
+        // walks all of A as before: Graph500 scale 22, 77 % in hub rows, 34.0 against 28-33 ms per launch)
+        const bool mostly_hub = plan.hub.cells != nullptr && plan.mode_partials[kModeStretch] * 3 >= count;
         if (column_major) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm, plan.cells, plan.qstage, plan.hub.cells ? &plan.hub : nullptr,
-                                       plan.ga.runs != nullptr, plan.p0.nlong != 0, desc_only);
+                                       plan.ga.runs != nullptr && !mostly_hub, plan.p0.nlong != 0, desc_only, mostly_hub);
         tm.end(PH_MUL);
         if (beside) {
             ctx->fork_window = false;
@@ -1452,12 +1455,12 @@ template <class T> struct OuterProducer : Producer<T> {
     bool short_gathered = false;  // the short rows are gathered (their chunks: kChunkSkip): a panel without long rows multiplies nothing
     void produce(uint64_t r0, uint64_t r1, bool whole, uint64_t base, uint64_t count, Part<T> *stage,
                  PhaseTimer &tm, const uint32_t *cells, Part<T> *qstage, const HubArgs *hub = nullptr, bool compact = false, bool has_long = true,
-                 bool desc_only = false) override {
+                 bool desc_only = false, bool walk_all = false) override {
         if (nothing_staged) return;
         if (short_gathered && !has_long) return;
         hipStream_t s = ctx->stream;
         const uint64_t nk = k1 - k0;
-        const bool ind = (compact || short_gathered) && elist && nnz;
+        const bool ind = (compact || short_gathered) && elist && nnz && !walk_all;
         if (ind) {
             const PanelKeepFlag keep{a_rowidx, chunk_off, e0, (uint32_t)r0, r1, desc_only ? 1u : 0u};
             device_exclusive_scan<PanelKeepFlag, uint32_t>(keep, nnz, kscan, kscan_tmp, s);
@@ -1503,7 +1506,7 @@ template <class T> struct PartsProducer : Producer<T> {
     const int64_t *const *d_rowptrs; const uint32_t *const *d_colidxs; const T *const *d_valss;
     int nparts;
     const uint64_t *row_off;
-    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &, const uint32_t *, Part<T> *, const HubArgs *, bool, bool, bool) override {
+    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &, const uint32_t *, Part<T> *, const HubArgs *, bool, bool, bool, bool) override {
         const uint64_t nr = r1 - r0;
         parts_scatter_kernel<T><<<grid_for(nr * kWave, 256), 256, 0, ctx->stream>>>(d_rowptrs, d_colidxs, d_valss, nparts,
                                                                                     r0, r1, row_off, base, stage);
@@ -1516,7 +1519,7 @@ template <class T> struct RecordPartsProducer : Producer<T> {
     int nparts;
     const uint64_t *row_off;
     const std::function<void(uint64_t, uint64_t)> *before = nullptr;   // called with the panel's rows before its records are read
-    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &, const uint32_t *, Part<T> *, const HubArgs *, bool, bool, bool) override {
+    void produce(uint64_t r0, uint64_t r1, bool, uint64_t base, uint64_t, Part<T> *stage, PhaseTimer &, const uint32_t *, Part<T> *, const HubArgs *, bool, bool, bool, bool) override {
         if (before) (*before)(r0, r1);
         const uint64_t nr = r1 - r0;
         parts_scatter_rec_kernel<T><<<grid_for(nr * kWave, 256), 256, 0, ctx->stream>>>(d_rowptrs, d_recs, nparts, r0, r1, row_off, base, stage);
