@@ -1057,10 +1057,9 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
                                                                            nullptr, 0u, nullptr, nullptr, nullptr, desc, nullptr, nullptr, io.rowfirst0);
     }
     uint64_t *tile_status = sc.get<uint64_t>(ntot);
-    // ticket counters: one word, or OSP_MERGE_SHARDS of them plus the arrival counter (osp_kernels.h, take_ticket; measured:
-    // no gain while the look-back is on -- the chain and the hash count bound the kernel, not the word -- so the default is 1)
-    static const uint32_t want_shards = getenv("OSP_MERGE_SHARDS") ? std::min(std::max(atoi(getenv("OSP_MERGE_SHARDS")), 1), 16) : 1;
-    const uint32_t nshards = ntot >= 1024 ? want_shards : 1u;
+    // ticket counters: one word (the kernel also takes several plus an arrival counter -- osp_kernels.h, take_ticket; measured in
+    // round 3: no gain while the look-back is on -- the chain and the hash count bound the kernel, not the word; the switch is gone)
+    const uint32_t nshards = 1u;
     uint32_t *ticket = sc.get<uint32_t>((uint64_t)(nshards + 1) * kTicketStride);
     zero_async(s, {{tile_status, (uint64_t)ntot * sizeof(uint64_t)}, {ticket, (uint64_t)(nshards + 1) * kTicketStride * sizeof(uint32_t)}});
     dbg_sync(s, "tile planning, splits, over-long segments");
@@ -1268,7 +1267,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     zero_async(s, {{out_nnz, sizeof(uint64_t)}, {abort_word, sizeof(uint32_t)}});
     auto check_abort = [&](uint32_t flag) {
         if (flag) throw Error(OSP_ERR_HIP, "the merge made no progress for seconds (a tile's predecessors never published their sizes); "
-                                           "with OSP_MERGE_SHARDS > 1 that happens when fewer workgroups than shards ever run side by side");
+                                           "with several ticket shards that happens when fewer workgroups than shards ever run side by side");
     };
     // With several panels the plan of panel p+1 (VALU-bound: one workgroup per long row, histograms in LDS) runs on the
     // context's second stream beside the multiply of panel p (bound by its scattered stores, its waves mostly parked): the
@@ -1681,9 +1680,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
     uint64_t P = 0;
     // Row-wise variant (cfg.algorithm): rows of up to one tile of partial products are computed inside the tile kernel
     // from the chunk table; B's offsets must fit 32 bits for it (otherwise the outer-product path runs as usual)
-    // (debugging aid: OSP_ALGORITHM=rowwise|outer overrides the configuration, so that whole test suites can run either way)
-    const char *algo_env = getenv("OSP_ALGORITHM");
-    const int algo = algo_env ? (strcmp(algo_env, "rowwise") == 0 ? OSP_ALGO_ROWWISE : OSP_ALGO_OUTER) : cfg.algorithm;
+    const int algo = cfg.algorithm;
     if (algo != OSP_ALGO_OUTER && algo != OSP_ALGO_ROWWISE) throw Error(OSP_ERR_ARG, "unknown algorithm");
     const bool rowwise = algo == OSP_ALGO_ROWWISE && nnz && (uint64_t)nnz_b < 0xffffffffull && nnz < 0xffffffffull && !partials_only;
     ChunkTable<T> ct{};

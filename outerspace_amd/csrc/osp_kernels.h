@@ -1014,7 +1014,7 @@ __device__ __forceinline__ void lookback_publish(uint64_t *status, uint32_t t, u
 // smallest unfinished tile is the next ticket of its shard, so some workgroup of that shard that is running (or starts)
 // takes it; that needs at least S workgroups of the launch to get to run side by side at some time, where the single
 // counter needs one.  The look-back therefore gives up after kLookbackSpinLimit fruitless rounds (seconds), raises the
-// product's abort word, and the host reports an error instead of a hang; OSP_MERGE_SHARDS=1 is the single counter.
+// product's abort word, and the host reports an error instead of a hang; (the library launches with one counter).
 constexpr int kTicketStride = 32;                    // 32-bit words between two shard counters
 constexpr uint32_t kLookbackSpinLimit = 1u << 22;
 __device__ __forceinline__ uint32_t take_ticket(uint32_t *ticket, uint32_t nshards, uint32_t &shard, uint32_t ntiles) {

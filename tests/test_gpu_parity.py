@@ -1353,3 +1353,35 @@ def test_long_row_of_tiny_chunks(port, _ctx_shared, K):
     assert got.info["direct_rows"] == (1 if K == 3000 else 0)
     assert_same(got, want)
     got.close()
+
+
+@pytest.mark.parametrize("switch", ["OSP_GATHER=1", "OSP_GATHER_OVER=0", "OSP_EXPAND_ROWS=0", "default"])
+def test_gathered_rows_partial_settings(_ctx_shared, port, monkeypatch, switch):
+    """Gathered rows with parts of the scheme switched off, so that the paths they replace stay alive beside
+    them in ONE product: planned long rows gathered but short rows staged by the compacted column-major multiply
+    (OSP_GATHER=1); rows with a range that exceeds a tile written by the multiply through cells while the others are gathered
+    (OSP_GATHER_OVER=0); rows beyond the planner staged column by column from the compacted list instead of row by row
+    (OSP_EXPAND_ROWS=0).  Skewed inputs with small planner limits: hub rows, over-long segments, rows of many blocks of
+    chunks, several panels.  All bit-identical to the oracle; the info says which rows were gathered."""
+    if switch != "default":
+        k, v = switch.split("=")
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("OSP_SPLIT_ROW_MAX", "20000")
+    monkeypatch.setenv("OSP_DIRECT_MAX", "12000")
+    c = _ctx_shared
+    c.algorithm = "outer"
+    for dt, preset, scale, cap in ((np.float64, "g500", 13, 0), (np.float32, "g500", 12, 60000), (np.float64, "mild", 14, 300000)):
+        n, rows, cols, vals = gen.rmat_coo(scale, 16, preset, seed=11, dtype=dt)
+        got, want = run_both(c, port, n, n, n, (rows, cols, vals), (rows, cols, vals), dt, partial_capacity=cap)
+        assert_same(got, want)
+        i = got.info
+        assert i["direct_rows"] > 0 and i["gathered_rows"] > 0 and i["gathered_runs"] > 0, i
+        if switch == "OSP_GATHER_OVER=0" and preset == "g500":
+            assert i["gathered_rows"] < i["direct_rows"], i     # the rows with an over-long range were written
+        if switch in ("default", "OSP_EXPAND_ROWS=0", "OSP_GATHER_OVER=0"):
+            assert i["gathered_short_partials"] > 0, i
+        if switch == "OSP_GATHER=1":
+            assert i["gathered_short_partials"] == 0, i
+        if switch == "default":
+            assert i["gathered_rows"] == i["direct_rows"], i
+        got.close()
