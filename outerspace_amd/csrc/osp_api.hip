@@ -768,7 +768,9 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
         GatherPlan gp{};
         RunDesc<T> *runs = nullptr;
         // (the run table is addressed with 32 bits; a panel whose bound does not fit writes its direct rows as before)
-        if (ds->gather && nrund && nrd < 0xffffffffull) {
+        // (debugging aid: OSP_GATHER_MAX_RUNS lowers that limit, so that a test reaches the fallback)
+        static const uint64_t max_runs = getenv("OSP_GATHER_MAX_RUNS") ? strtoull(getenv("OSP_GATHER_MAX_RUNS"), nullptr, 10) : 0xffffffffull;
+        if (ds->gather && nrund && nrd < max_runs) {
             runs = sc.get<RunDesc<T>>(std::max<uint64_t>(nrd, 1));
             pl.vrun_off = sc.get<uint32_t>(pl.nvirt + 1);
             pl.vrun_end = sc.get<uint32_t>(pl.nvirt + 1);
@@ -1330,7 +1332,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
             // what is left for the column-major multiply: rows written through cells -- hub rows, direct rows with an over-long range
             desc_only = true;
             const uint32_t nw = plan.nwritten ? d2h(plan.nwritten, s) : 0u;
-            column_major = plan.hub.cells != nullptr || nw != 0;
+            column_major = plan.hub.cells != nullptr || nw != 0 || (plan.mode_rows[kModeDirect] != 0 && plan.ga.runs == nullptr);   // (a panel whose run table would not fit 32 bits writes its direct rows)
         }
         // (the compacted multiply pays where few chunks are left to write; a panel whose hub rows hold a third of its products
         // walks all of A as before: Graph500 scale 22, 77 % in hub rows, 34.0 against 28-33 ms per launch)

@@ -69,7 +69,7 @@ print("OVERLAP_OK")
 """
 
 
-@pytest.mark.parametrize("mode", ["OSP_POISON", "OSP_GUARD"])
+@pytest.mark.parametrize("mode", ["OSP_POISON", "OSP_GUARD", "OSP_GATHER_MAX_RUNS"])
 def test_plan_overlap_under_poison_and_guard(mode, port):
     """The plan of panel p+1 runs on the context's second stream beside the multiply of panel p, and the buffer pool is not
     stream-aware (osp_api.hip, Context::fork_window).  Products of many panels with the plans overlapped, in a process of
@@ -78,5 +78,10 @@ def test_plan_overlap_under_poison_and_guard(mode, port):
     to the oracle, and the library's own check that nothing is released inside the fork window stays silent."""
     env = dict(os.environ, OSP_TEST_ROOT=ROOT, OSP_DIRECT_MIN_NNZ="0", OSP_PLAN_OVERLAP="1")
     env[mode] = "1"
+    if mode == "OSP_GATHER_MAX_RUNS":
+        # not a checking mode but a limit (read once per process): panels whose run table would hold 300 descriptors or more
+        # write their planned rows through the multiply's cells while the short rows stay gathered -- the fallback of a panel
+        # whose run table does not fit 32-bit addressing
+        env[mode] = "300"
     r = subprocess.run([sys.executable, "-c", _OVERLAP_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OVERLAP_OK" in r.stdout, r.stdout + r.stderr
