@@ -609,6 +609,18 @@ struct DirectSrc {
     // kernel forms their records from run descriptors.  a_vals: indexed by `perm`; gstat: rows / partial products / runs (device)
     bool gather = false;
     bool expand_rows = false;   // the short rows are gathered too: plainly staged long rows are expanded row by row (expand_rows_kernel)
+    // ... and then nobody reads the chunk offsets unless a panel has rows written through cells (hub rows, the fallbacks of
+    // the gathered rows): they are made when the first such panel is planned (ensure_chunk_off), not by every product
+    // (sym_scatter_offsets_kernel: 1 ms of scattered 8-byte stores on the headline, 0.08 of the web-Google shape's 2 ms)
+    mutable bool chunk_off_ready = true;
+    const uint32_t *rows_sorted = nullptr;
+    const uint64_t *row_off = nullptr;
+    uint64_t rw_cap = 0, nnz = 0;
+    void ensure_chunk_off(hipStream_t s) const {
+        if (chunk_off_ready) return;
+        sym_scatter_offsets_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(perm, off, rows_sorted, row_off, rw_cap, nnz, chunk_off);
+        chunk_off_ready = true;
+    }
     const void *a_vals = nullptr, *b_vals = nullptr;
     unsigned long long *gstat = nullptr;
 };
@@ -637,6 +649,7 @@ template <class T> struct PanelPlan {
     uint64_t *xjobbase = nullptr;     // expand_rows_kernel's jobs: first job of every long row (null: the multiply stages the rows)
     uint64_t xjobs_bound = 0, xpartials = 0;
     bool expand_ok = false;           // the panel's plainly staged long rows (if any) have jobs: the column-major multiply need not stage them
+    bool may_write = false;           // some planned rows of the panel may have been written through cells (OSP_GATHER_OVER=0)
     explicit PanelPlan(Context *c) : sc(c) {}
 };
 
@@ -781,8 +794,13 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
             pl.nwritten = gp.nwritten = sc.get<uint32_t>(1);
             zero_async(s, {{pl.nwritten, sizeof(uint32_t)}});
             gp.over = !(getenv("OSP_GATHER_OVER") && atoi(getenv("OSP_GATHER_OVER")) == 0);
+            pl.may_write = !gp.over;
             pl.ga.runs = runs; pl.ga.b_colidx = ds->b_colidx; pl.ga.b_vals = (const T *)ds->b_vals;
         }
+        // rows the multiply will write -- direct rows that are not gathered, hub rows -- get descriptors in the chunk offsets, and
+        // the gathered rows beside them their skip marks: the offsets must exist first
+        if (!(runs && gp.over) || (hub_b && pl.nblocks)) ds->ensure_chunk_off(s);
+        gp.mark_skipped = ds->chunk_off_ready ? 1u : 0u;
         tm.begin(PH_PLAN_K, s);
         direct_plan_kernel<T><<<nlong, kDirectThreads, 0, s>>>(pl.p0.long_rows, nlong, pl.hmode, pl.hbits, nseg, pl.vbase, pl.hoff, pl.cellbase, row_off,
                                                               colbits, kCap, ds->rowfirst, ds->off, ds->bs, ds->perm, ds->b_colidx, pl.vrow_off,
@@ -858,6 +876,7 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
             tm.end(PH_HUB_K);
         } else {
             uint32_t *hcells = sc.get<uint32_t>(ncells);
+            ds->ensure_chunk_off(s);
             hub_plan_kernel<true><<<(unsigned)pl.nblocks, kHubThreads, hub_lds, s>>>(pl.p0.long_rows, nlong, pl.blkbase, pl.hbase, pl.hbits, pl.nstretch, row_off,
                                                                               ds->rowfirst, ds->off, ds->bs, ds->perm, ds->b_colidx, ds->hub, pl.ghist,
                                                                               pl.hoff, nullptr, jobruns, hcells, ds->chunk_off);
@@ -1331,12 +1350,14 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         if (count && plan.expand_ok) {
             // what is left for the column-major multiply: rows written through cells -- hub rows, direct rows with an over-long range
             desc_only = true;
-            const uint32_t nw = plan.nwritten ? d2h(plan.nwritten, s) : 0u;
+            // (with every planned row gathered -- the default -- nothing can have been counted: no round trip)
+            const uint32_t nw = (plan.nwritten && plan.may_write) ? d2h(plan.nwritten, s) : 0u;
             column_major = plan.hub.cells != nullptr || nw != 0 || (plan.mode_rows[kModeDirect] != 0 && plan.ga.runs == nullptr);   // (a panel whose run table would not fit 32 bits writes its direct rows)
         }
         // (the compacted multiply pays where few chunks are left to write; a panel whose hub rows hold a third of its products
         // walks all of A as before: Graph500 scale 22, 77 % in hub rows, 34.0 against 28-33 ms per launch)
         const bool mostly_hub = plan.hub.cells != nullptr && plan.mode_partials[kModeStretch] * 3 >= count;
+        if (column_major && ds) ds->ensure_chunk_off(s);
         if (column_major) prod.produce(r0, r1, npanels == 1 && all_rows, base, count, stage, tm, plan.cells, plan.qstage, plan.hub.cells ? &plan.hub : nullptr,
                                        plan.ga.runs != nullptr && !mostly_hub, plan.p0.nlong != 0, desc_only, mostly_hub);
         tm.end(PH_MUL);
@@ -1720,7 +1741,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         Scratch ss(ctx);
         Scratch &keep = (rowwise || direct || gather_short) ? sc : ss;  // the chunk table outlives the symbolic phase
         uint32_t *ka = ss.get<uint32_t>(nnz), *pa = ss.get<uint32_t>(nnz), *kb = ss.get<uint32_t>(nnz), *pb = ss.get<uint32_t>(nnz);
-        uint32_t *rows_sorted = ss.get<uint32_t>(nnz), *perm = keep.get<uint32_t>(nnz), *w_sorted = ss.get<uint32_t>(nnz);
+        uint32_t *rows_sorted = (gather_short ? keep : ss).template get<uint32_t>(nnz), *perm = keep.get<uint32_t>(nnz), *w_sorted = ss.get<uint32_t>(nnz);
         uint32_t *bs_sorted = (rowwise || direct || gather_short) ? keep.get<uint32_t>(nnz) : nullptr;
         uint32_t *rowfirst = keep.get<uint32_t>(M + 1);
         uint32_t *hist = ss.get<uint32_t>(rs_hist_entries(nnz));
@@ -1737,7 +1758,9 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{w_sorted}, nnz, offs_sorted, scan_tmp, s);
         sym_row_offsets_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(rows_sorted, offs_sorted, nnz, M, row_off, rowfirst);
         const uint64_t rw_cap = (rowwise || gather_short) ? (uint64_t)TileCap<T>::value : 0ull;   // rows the multiply skips
-        sym_scatter_offsets_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(perm, offs_sorted, rows_sorted, row_off, rw_cap, nnz, chunk_off);
+        // (lazily where only rows written through cells would read them: DirectSrc::ensure_chunk_off)
+        const bool expand_rows_on = gather_short && !(getenv("OSP_EXPAND_ROWS") && atoi(getenv("OSP_EXPAND_ROWS")) == 0);
+        if (!expand_rows_on) sym_scatter_offsets_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(perm, offs_sorted, rows_sorted, row_off, rw_cap, nnz, chunk_off);
         // (the product proper reads P together with the size of the result, merge_pipeline: one stream round trip less)
         if (partials_only || rowwise || row_sharded) P = d2h(offs_sorted + nnz, s);
         else P = kPartialsOnDevice;
@@ -1747,7 +1770,8 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
             // gathered rows (osp_kernels.h): on unless OSP_GATHER=0 (debugging aid, A/B timing: every direct row is then written
             // by the multiply, as until round 4) or the row-wise variant runs (its tile kernel is another instantiation)
             dsrc.gather = gather_ok && gather_env >= 1;
-            dsrc.expand_rows = gather_short && !(getenv("OSP_EXPAND_ROWS") && atoi(getenv("OSP_EXPAND_ROWS")) == 0);
+            dsrc.expand_rows = expand_rows_on;
+            if (expand_rows_on) { dsrc.chunk_off_ready = false; dsrc.rows_sorted = rows_sorted; dsrc.row_off = row_off; dsrc.rw_cap = rw_cap; dsrc.nnz = nnz; }
             dsrc.a_vals = a_vals + e0; dsrc.b_vals = b_vals;
             if (dsrc.gather) {
                 dsrc.gstat = (unsigned long long *)sc.get<uint64_t>(3);

@@ -673,6 +673,7 @@ struct GatherPlan {
     uint32_t *rowruns = nullptr;
     uint32_t *nwritten = nullptr;       // += 1 per direct row that is NOT gathered: rows the multiply writes through cells
     uint32_t over = 1;                  // rows with a range that exceeds a tile are gathered too
+    uint32_t mark_skipped = 1;          // the chunk offsets exist (a column-major multiply may read them): gathered chunks get kChunkSkip
 };
 // gstat[0..2] += gathered rows, their partial products, their runs (few workgroups: they end in atomics on three hot words --
 // one set per ROW inside the planner made it twice as slow)
@@ -957,7 +958,7 @@ __global__ __launch_bounds__(kDirectThreads, 8) void direct_plan_kernel(
                     if (g == G - 1) { cursor[t] = run; ncur[t] = nrun; }
                 }
             }
-            for (uint32_t cl = tid; cl < nb; cl += NT) chunk_off[perm[c0 + cb + cl]] = kChunkSkip;
+            if (gp.mark_skipped) { for (uint32_t cl = tid; cl < nb; cl += NT) chunk_off[perm[c0 + cb + cl]] = kChunkSkip; }
             __syncthreads();
             OSP_PLAN_MARK(5);
         }
