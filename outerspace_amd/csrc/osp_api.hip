@@ -621,7 +621,8 @@ struct DirectSrc {
         sym_scatter_offsets_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(perm, off, rows_sorted, row_off, rw_cap, nnz, chunk_off);
         chunk_off_ready = true;
     }
-    const void *a_vals = nullptr, *b_vals = nullptr;
+    const void *a_vals = nullptr, *b_vals = nullptr;   // a_vals: indexed by `perm`, or (av_in_order) the values in (row, k) order
+    bool av_in_order = false;
     unsigned long long *gstat = nullptr;
 };
 
@@ -794,6 +795,7 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
             pl.nwritten = gp.nwritten = sc.get<uint32_t>(1);
             zero_async(s, {{pl.nwritten, sizeof(uint32_t)}});
             gp.over = !(getenv("OSP_GATHER_OVER") && atoi(getenv("OSP_GATHER_OVER")) == 0);
+            gp.av_in_order = ds->av_in_order ? 1u : 0u;
             pl.may_write = !gp.over;
             pl.ga.runs = runs; pl.ga.b_colidx = ds->b_colidx; pl.ga.b_vals = (const T *)ds->b_vals;
         }
@@ -1248,38 +1250,37 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
                 (unsigned long long)M, (unsigned long long)N, (unsigned long long)P, (unsigned long long)cap_c, cap_c * E / 1e9,
                 free_b / 1e9, (unsigned long long)cap, cap * E / 1e9);
     std::vector<uint64_t> bounds{r_lo};  // absolute row ids
-    std::vector<uint64_t> h_off_v;         // row_off[r_lo .. r_hi] on the host (multi-panel only)
+    std::vector<uint64_t> boff{off_lo};  // row_off at the bounds (multi-panel only)
     if (P <= cap && !(cuts && !cuts->empty())) {
         bounds.push_back(r_hi);
+        boff.push_back(off_lo + P);
     } else {
-        h_off_v.resize(M + 1);
-        copy_d2h(h_off_v.data(), d_row_off + r_lo, (M + 1) * sizeof(uint64_t), s);
-        uint64_t r = 0;
-        size_t ci = 0;
-        while (r < M) {
-            // largest r1 with row_off[r1] - row_off[r] <= cap
-            uint64_t r1 = std::upper_bound(h_off_v.begin() + r, h_off_v.end(), h_off_v[r] + cap) - h_off_v.begin() - 1;
-            if (r1 <= r)
-                throw Error(OSP_ERR_CAPACITY, "output row " + std::to_string(r_lo + r) + " has " +
-                            std::to_string(h_off_v[r + 1] - h_off_v[r]) + " partial products, staging capacity is " +
-                            std::to_string(cap));
-            r1 = std::min(r1, M);
-            if (cuts) {
-                while (ci < cuts->size() && (*cuts)[ci] <= r_lo + r) ci++;
-                if (ci < cuts->size() && (*cuts)[ci] < r_lo + r1) r1 = (*cuts)[ci] - r_lo;
-            }
-            bounds.push_back(r_lo + r1);
-            r = r1;
-        }
+        // The panels' bounds are found on the device by one wave (round 5; until then all M + 1 row offsets came to the host:
+        // 33 MB through a fresh vector, 6.5 ms of the headline product with the device idle): at most kMaxPanels of them, the
+        // bounds and the offsets there in one small read-back.
+        constexpr uint32_t kMaxPanels = 4096;
+        const uint32_t ncuts = cuts ? (uint32_t)cuts->size() : 0u;
+        uint64_t *d_b = sc.get<uint64_t>(2ull * (kMaxPanels + 1) + 2), *d_cuts = sc.get<uint64_t>(std::max<uint32_t>(ncuts, 1));
+        if (ncuts) copy_h2d(d_cuts, cuts->data(), ncuts * sizeof(uint64_t), s);
+        panel_bounds_kernel<<<1, kWave, 0, s>>>(d_row_off, r_lo, M, cap, d_cuts, ncuts, kMaxPanels, d_b);
+        std::vector<uint64_t> hb(2ull * (kMaxPanels + 1) + 2);
+        copy_d2h(hb.data(), d_b, hb.size() * sizeof(uint64_t), s);
+        const uint64_t np = hb[0], bad = hb[1];
+        if (bad != ~0ull)
+            throw Error(OSP_ERR_CAPACITY, "output row " + std::to_string(bad) + " has more partial products than the staging capacity of " +
+                        std::to_string(cap) + ", or the product needs more than " + std::to_string(kMaxPanels) + " panels");
+        for (uint64_t p = 1; p <= np; p++) { bounds.push_back(hb[2 + p]); boff.push_back(hb[2 + (kMaxPanels + 1) + p]); }
+        boff[0] = hb[2 + (kMaxPanels + 1)];
     }
-    const uint64_t *h_off = h_off_v.empty() ? nullptr : h_off_v.data() - r_lo;  // indexed by absolute row id
     const bool all_rows = r_lo == 0 && r_hi == M_all;
     const uint32_t npanels = (uint32_t)bounds.size() - 1;
     res->info.panels = npanels;
+    // staging offset of panel p's first row, and its number of partial products
+    auto panel_base = [&](uint32_t p) { return (npanels == 1) ? off_lo : boff[p]; };
+    auto panel_count = [&](uint32_t p) { return (npanels == 1) ? P : boff[p + 1] - boff[p]; };
     uint64_t max_panel = 0, max_rows_panel = 0;
     for (uint32_t p = 0; p < npanels; p++) {
-        uint64_t cnt = (npanels == 1) ? P : h_off[bounds[p + 1]] - h_off[bounds[p]];
-        max_panel = std::max(max_panel, cnt);
+        max_panel = std::max(max_panel, panel_count(p));
         max_rows_panel = std::max(max_rows_panel, bounds[p + 1] - bounds[p]);
     }
     Part<T> *stage = sc.get<Part<T>>(max_panel);
@@ -1309,8 +1310,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     typedef std::unique_ptr<PanelPlan<T>> PlanPtr;
     auto plan_one = [&](uint32_t p, bool beside) -> PlanPtr {
         const uint64_t r0 = bounds[p], r1 = bounds[p + 1];
-        const uint64_t base = (npanels == 1) ? off_lo : h_off[r0];
-        const uint64_t count = (npanels == 1) ? P : h_off[r1] - base;
+        const uint64_t base = panel_base(p), count = panel_count(p);
         PlanPtr pl(new PanelPlan<T>(ctx));
         if (beside) {
             AuxScope scope(ctx);
@@ -1330,19 +1330,18 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     // the multiply of panel p, then -- beside it -- the plan of panel p+1
     auto multiply_and_plan_next = [&](uint32_t p, PanelPlan<T> &plan, PlanPtr &nxt) {
         const uint64_t r0 = bounds[p], r1 = bounds[p + 1];
-        const uint64_t base = (npanels == 1) ? off_lo : h_off[r0];
-        const uint64_t count = (npanels == 1) ? P : h_off[r1] - base;
+        const uint64_t base = panel_base(p), count = panel_count(p);
         if (plan.p0.nlong) plan.qstage = plan.sc.template get<Part<T>>(plan.nh);   // (not before: the plan may be a panel ahead)
         const bool beside = overlap && p + 1 < npanels;
         if (beside) { OSP_HIP(hipEventRecord(ctx->aux_fork, s)); ctx->fork_window = true; ctx->releases_in_fork_window = 0; }
         struct WindowEnd { Context *c; ~WindowEnd() { c->fork_window = false; } } window_end{ctx};
         tm.begin(PH_MUL);
-        bool column_major = count != 0, desc_only = false;
+        bool column_major = count != 0 && !(sr && plan.p0.nlong == 0), desc_only = false;   // (short rows gathered, no long row: nothing is staged)
         if (count && plan.xjobbase && plan.xjobs_bound) {
             tm.begin(PH_EXPAND_K);
             expand_rows_kernel<T><<<(unsigned)plan.xjobs_bound, kExpandThreads, 0, s>>>(plan.p0.long_rows, plan.p0.nlong, plan.xjobbase, d_row_off, base, ds->rowfirst,
-                                                                                     ds->off, ds->bs, ds->perm, (const T *)ds->a_vals, ds->b_colidx,
-                                                                                     (const T *)ds->b_vals, stage);
+                                                                                     ds->off, ds->bs, ds->av_in_order ? nullptr : ds->perm, (const T *)ds->a_vals,
+                                                                                     ds->b_colidx, (const T *)ds->b_vals, stage);
             tm.end(PH_EXPAND_K);
             res->info.expand_launches++;
             res->info.expand_partials += plan.xpartials;
@@ -1384,7 +1383,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
         PlanPtr cur, nxt;
         for (uint32_t p = 0; p < npanels; p++) {
             const uint64_t r0 = bounds[p], r1 = bounds[p + 1];
-            const uint64_t base = (npanels == 1) ? off_lo : h_off[r0];
+            const uint64_t base = panel_base(p);
             if (!cur) cur = plan_one(p, false);
             PanelPlan<T> &plan = *cur;
             multiply_and_plan_next(p, plan, nxt);
@@ -1414,7 +1413,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     PlanPtr cur, nxt;
     for (uint32_t p = 0; p < npanels; p++) {
         const uint64_t r0 = bounds[p], r1 = bounds[p + 1];
-        const uint64_t base = (npanels == 1) ? off_lo : h_off[r0];
+        const uint64_t base = panel_base(p);
         // ---- plan (unless made beside the previous panel's multiply), multiply (or scatter of CSR parts) ----
         if (!cur) cur = plan_one(p, false);
         PanelPlan<T> &plan = *cur;
@@ -1750,11 +1749,16 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
         uint64_t *scan_tmp = ss.get<uint64_t>(scan_scratch_entries(std::max<uint64_t>(nnz, M + 1)));
         // (row, k) order of A's non-zeros; the last sort pass also looks up each chunk's length
         const bool table = rowwise || direct || gather_short;   // keep the chunk table: (length, B row) pairs in `w`
-        uint32_t *w = ss.get<uint32_t>(table ? 2 * nnz : nnz);
+        // (gathered rows: the A values ride along, so that the run descriptors' makers read them in (row, k) order)
+        const bool with_av = gather_ok && gather_env >= 1 && (direct || gather_short);
+        T *av_sorted = with_av ? keep.get<T>(nnz) : nullptr;
+        uint32_t *w = ss.get<uint32_t>(with_av ? 4 * nnz : table ? 2 * nnz : nnz);
         uint32_t *bs = table ? w : nullptr;
-        sym_chunk_len_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(a_colptr, b_rowptr, k0, k1, e0, nnz, w, bs);
-        device_sort_rows<SymEpilogue>(a_rowidx + e0, nnz, std::max(1, bits_for(M)), ka, pa, kb, pb, hist, hist_tmp,
-                                      SymEpilogue{w, bs, rows_sorted, perm, w_sorted, bs_sorted}, s, ctx->rank_atomic);
+        sym_chunk_len_kernel<<<grid_for(nnz, 256), 256, 0, s>>>(a_colptr, b_rowptr, k0, k1, e0, nnz, w, bs,
+                                                                with_av ? reinterpret_cast<const uint32_t *>(a_vals) : nullptr, (uint32_t)(sizeof(T) / 4));
+        SymEpilogue sym_ep{w, bs, rows_sorted, perm, w_sorted, bs_sorted};
+        if (with_av) { sym_ep.av_sorted = av_sorted; sym_ep.vwords = (uint32_t)(sizeof(T) / 4); }
+        device_sort_rows<SymEpilogue>(a_rowidx + e0, nnz, std::max(1, bits_for(M)), ka, pa, kb, pb, hist, hist_tmp, sym_ep, s, ctx->rank_atomic);
         device_exclusive_scan<LoadU32As64, uint64_t>(LoadU32As64{w_sorted}, nnz, offs_sorted, scan_tmp, s);
         sym_row_offsets_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(rows_sorted, offs_sorted, nnz, M, row_off, rowfirst);
         const uint64_t rw_cap = (rowwise || gather_short) ? (uint64_t)TileCap<T>::value : 0ull;   // rows the multiply skips
@@ -1772,7 +1776,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
             dsrc.gather = gather_ok && gather_env >= 1;
             dsrc.expand_rows = expand_rows_on;
             if (expand_rows_on) { dsrc.chunk_off_ready = false; dsrc.rows_sorted = rows_sorted; dsrc.row_off = row_off; dsrc.rw_cap = rw_cap; dsrc.nnz = nnz; }
-            dsrc.a_vals = a_vals + e0; dsrc.b_vals = b_vals;
+            dsrc.a_vals = with_av ? (const void *)av_sorted : (const void *)(a_vals + e0); dsrc.av_in_order = with_av; dsrc.b_vals = b_vals;
             if (dsrc.gather) {
                 dsrc.gstat = (unsigned long long *)sc.get<uint64_t>(3);
                 zero_async(s, {{dsrc.gstat, 3 * sizeof(uint64_t)}});
@@ -1785,7 +1789,7 @@ static void spgemm_impl(Context *ctx, Result *res, uint64_t M, uint64_t K, uint6
             device_exclusive_scan<ShortRunFlag, uint32_t>(sf, nnz, cidx, cidx_tmp, s);
             RunDesc<T> *runs0 = sc.get<RunDesc<T>>(nnz);   // (bound: every chunk; the count stays on the device)
             uint32_t *rowfirst0 = sc.get<uint32_t>(M + 1);
-            short_runs_kernel<T><<<grid_for(nnz, 256), 256, 0, s>>>(sf, cidx, nnz, bs_sorted, perm, a_vals + e0, runs0);
+            short_runs_kernel<T><<<grid_for(nnz, 256), 256, 0, s>>>(sf, cidx, nnz, bs_sorted, av_sorted, runs0);
             short_rowfirst_kernel<<<grid_for(M + 1, 256), 256, 0, s>>>(rowfirst, cidx, M, rowfirst0);
             srun = ShortRuns<T>{runs0, rowfirst0, b_colidx, b_vals};
         }

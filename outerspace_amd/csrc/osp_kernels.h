@@ -277,6 +277,30 @@ __global__ void panel_columns_kernel(const int64_t *a_colptr, const uint32_t *a_
     a_cnt[t] = (uint32_t)(hi - lo);
     prod[t] = (hi - lo) * (uint64_t)(b_rowptr[k + 1] - b_rowptr[k]);
 }
+// The row panels of a product that does not fit the staging capacity (ONE wave): consecutive rows whose partial products
+// fit `cap`, never across one of `cuts` (ascending absolute row ids; the multi-GPU merge ends its panels where the pieces it
+// receives end).  out[0] = number of panels, out[1] = ~0 or the first row that alone exceeds the capacity (or the row at which
+// maxp panels were used up), out[2 + p] = first row of panel p (and r_lo + M behind the last), out[2 + maxp + 1 + p] = its staging offset.
+__global__ void panel_bounds_kernel(const uint64_t *row_off, uint64_t r_lo, uint64_t M, uint64_t cap, const uint64_t *cuts, uint32_t ncuts,
+                                    uint32_t maxp, uint64_t *out) {
+    const uint64_t *off = row_off + r_lo;
+    uint64_t r = 0, bad = ~0ull;
+    uint32_t p = 0, ci = 0;
+    if (lane_id() == 0) { out[2] = r_lo; out[2 + maxp + 1] = off[0]; }
+    while (r < M) {
+        if (p == maxp) { bad = r_lo + r; break; }
+        // largest r1 with off[r1] - off[r] <= cap
+        uint64_t r1 = wave_upper_bound(off, r, M + 1, off[r] + cap) - 1;
+        if (r1 <= r) { bad = r_lo + r; break; }
+        r1 = min(r1, M);
+        while (ci < ncuts && cuts[ci] <= r_lo + r) ci++;
+        if (ci < ncuts && cuts[ci] < r_lo + r1) r1 = cuts[ci] - r_lo;
+        p++;
+        if (lane_id() == 0) { out[2 + p] = r_lo + r1; out[2 + maxp + 1 + p] = off[r1]; }
+        r = r1;
+    }
+    if (lane_id() == 0) { out[0] = p; out[1] = bad; }
+}
 struct LoadU64 {
     const uint64_t *p;
     __device__ uint64_t operator()(uint64_t i) const { return p[i]; }
@@ -761,7 +785,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_rows_kernel(
         const uint64_t o0 = cv ? ct_off[cq] : ~0ull, o1 = cv ? ct_off[cq + 1] : ~0ull;
         if (wave_bcast(o0, 0u) >= p1) break;   // (wave-uniform)
         const uint32_t bsv = cv ? ct_bs[cq] : 0u;
-        const T av = cv ? a_vals[perm[cq]] : T(0);
+        const T av = cv ? (perm ? a_vals[perm[cq]] : a_vals[cq]) : T(0);   // (perm == nullptr: the values are in chunk order)
         // the group's products inside the slice
         const uint64_t g0 = max(wave_bcast(o0, 0u), p0);
         const uint32_t nval = min((uint32_t)kWave, c1 - c);
@@ -1125,14 +1149,13 @@ struct ShortRunFlag {
     __device__ uint32_t operator()(uint64_t c) const { return off[c + 1] > off[c] ? 1u : 0u; }
 };
 template <class T>
-__global__ void short_runs_kernel(ShortRunFlag f, const uint32_t *cidx, uint64_t nnz, const uint32_t *bs, const uint32_t *perm, const T *a_vals,
-                                  RunDesc<T> *runs0) {
+__global__ void short_runs_kernel(ShortRunFlag f, const uint32_t *cidx, uint64_t nnz, const uint32_t *bs, const T *av_sorted, RunDesc<T> *runs0) {
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nnz || !f(c)) return;
     RunDesc<T> rd;
     rd.dst = (uint32_t)f.off[c];
     rd.src = bs[c];
-    rd.av = a_vals[perm[c]];
+    rd.av = av_sorted[c];
     runs0[cidx[c]] = rd;
 }
 __global__ void short_rowfirst_kernel(const uint32_t *rowfirst, const uint32_t *cidx, uint64_t M, uint32_t *rowfirst0) {

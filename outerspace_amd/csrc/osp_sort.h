@@ -212,10 +212,21 @@ struct SymEpilogue {
     const uint32_t *w;   // chunk length per A entry, CSC order -- or, with the B rows wanted, (length, first entry of the B row)
     const uint32_t *bs;  // non-null: `w` holds pairs (one 8-byte gather per chunk instead of two 4-byte ones from two arrays)
     uint32_t *rows_sorted, *perm, *w_sorted, *bs_sorted;
+    // gathered rows (osp_kernels.h): `w` holds quads (length, B row, the entry's A value in vwords = 1 or 2 words) and the value
+    // goes along to av_sorted -- the ONE gather by `pos` of this pass brings it, where a later gather of a_vals[perm[t]] by
+    // every consumer fetched a line per value (short_runs_kernel: 1.5 ms of the headline)
+    void *av_sorted = nullptr;
+    uint32_t vwords = 0;
     __device__ void operator()(uint64_t t, uint32_t row, uint32_t pos) const {
         rows_sorted[t] = row;
         perm[t] = pos;
-        if (bs_sorted) {   // (row-wise variant and direct rows: the chunk table)
+        if (av_sorted) {
+            const uint4 q = reinterpret_cast<const uint4 *>(w)[pos];
+            w_sorted[t] = q.x;
+            bs_sorted[t] = q.y;
+            if (vwords == 2) reinterpret_cast<uint2 *>(av_sorted)[t] = make_uint2(q.z, q.w);
+            else reinterpret_cast<uint32_t *>(av_sorted)[t] = q.z;
+        } else if (bs_sorted) {   // (row-wise variant and direct rows: the chunk table)
             const uint2 p = reinterpret_cast<const uint2 *>(w)[pos];
             w_sorted[t] = p.x;
             bs_sorted[t] = p.y;
@@ -226,8 +237,9 @@ struct SymEpilogue {
 };
 // w[t] = nnz(B[k,:]) for the t-th non-zero of A's shard (CSC order, column k); with bs != nullptr: w holds the pairs
 // (nnz(B[k,:]), b_rowptr[k]) -- 2 * nnz words -- and bs itself is only the switch
+// a_vals_raw != nullptr: quads (nnz(B[k,:]), b_rowptr[k], the entry's value in vwords words) -- 4 * nnz words
 __global__ void sym_chunk_len_kernel(const int64_t *a_colptr, const int64_t *b_rowptr, uint64_t k0, uint64_t k1, int64_t e0,
-                                     uint64_t nnz, uint32_t *w, uint32_t *bs) {
+                                     uint64_t nnz, uint32_t *w, uint32_t *bs, const uint32_t *a_vals_raw = nullptr, uint32_t vwords = 0) {
     // the block's 256 consecutive entries lie in a short range of columns: two full searches per block (first and last
     // entry, a wave each), then every thread bisects that range only (~4 steps instead of ~22)
     __shared__ uint64_t krange[2];
@@ -243,7 +255,11 @@ __global__ void sym_chunk_len_kernel(const int64_t *a_colptr, const int64_t *b_r
     if (t >= nnz) return;
     const uint64_t k = upper_bound_dev(a_colptr, krange[0], krange[1] + 1, e0 + (int64_t)t) - 1;
     const uint32_t len = (uint32_t)(b_rowptr[k + 1] - b_rowptr[k]);
-    if (bs) reinterpret_cast<uint2 *>(w)[t] = make_uint2(len, (uint32_t)b_rowptr[k]);   // pairs: `w` has 2 * nnz words then
+    if (a_vals_raw) {
+        const uint64_t e = (uint64_t)e0 + t;
+        const uint32_t v0 = a_vals_raw[e * vwords], v1 = vwords == 2 ? a_vals_raw[e * vwords + 1] : 0u;
+        reinterpret_cast<uint4 *>(w)[t] = make_uint4(len, (uint32_t)b_rowptr[k], v0, v1);
+    } else if (bs) reinterpret_cast<uint2 *>(w)[t] = make_uint2(len, (uint32_t)b_rowptr[k]);   // pairs: `w` has 2 * nnz words then
     else w[t] = len;
 }
 

@@ -674,6 +674,7 @@ struct GatherPlan {
     uint32_t *nwritten = nullptr;       // += 1 per direct row that is NOT gathered: rows the multiply writes through cells
     uint32_t over = 1;                  // rows with a range that exceeds a tile are gathered too
     uint32_t mark_skipped = 1;          // the chunk offsets exist (a column-major multiply may read them): gathered chunks get kChunkSkip
+    uint32_t av_in_order = 0;           // a_vals holds the chunks' A values in (row, k) order (else: indexed through perm)
 };
 // gstat[0..2] += gathered rows, their partial products, their runs (few workgroups: they end in atomics on three hot words --
 // one set per ROW inside the planner made it twice as slow)
@@ -847,7 +848,7 @@ __global__ __launch_bounds__(kDirectThreads, 8) void direct_plan_kernel(
         __syncthreads();
         if (tid <= T) { nzc[tid] = 0; ncur[tid] = 0; if (tid < T) cursor[tid] = bcol_t; }
         // (the A values of a row of ONE block of chunks are fetched now -- two dependent loads -- and arrive during the walk)
-        if (!multi) { for (uint32_t cl = tid; cl < nc; cl += NT) avs[cl] = a_vals[perm[c0 + cl]]; }
+        if (!multi) { for (uint32_t cl = tid; cl < nc; cl += NT) avs[cl] = gp.av_in_order ? a_vals[c0 + cl] : a_vals[perm[c0 + cl]]; }
         __syncthreads();
         // A: (chunk, range) counts, block by block; runs per range
         for (uint32_t cb = 0; cb < nc; cb += CB) {
@@ -917,7 +918,7 @@ __global__ __launch_bounds__(kDirectThreads, 8) void direct_plan_kernel(
                 if (cb != have_cb || nb != have_nb) { have_E = load_block(cb, nb); have_cb = cb; have_nb = nb; }
                 for (uint32_t x = tid; x < nb * T; x += NT) { const uint32_t cl = x / T, t = x - cl * T; cellm[x] = rb[lutw + (uint64_t)(cb + cl) * Ta + t]; }
             }
-            if (multi) { for (uint32_t cl = tid; cl < nb; cl += NT) avs[cl] = a_vals[perm[c0 + cb + cl]]; }
+            if (multi) { for (uint32_t cl = tid; cl < nb; cl += NT) avs[cl] = gp.av_in_order ? a_vals[c0 + cb + cl] : a_vals[perm[c0 + cb + cl]]; }
             __syncthreads();
             for (uint32_t cl = tid; cl < nb; cl += NT) {   // where every range starts inside its chunk
                 uint32_t run = 0;
