@@ -1122,7 +1122,7 @@ def test_hub_rows_written_by_the_multiply(port, monkeypatch, _ctx_shared, hub, d
 @pytest.mark.parametrize("overlap", ["1", "0"])
 def test_next_panels_plan_runs_beside_the_multiply(port, monkeypatch, _ctx_shared, overlap):
     """A product of several panels plans panel p+1 on the context's second stream while panel p is multiplied
-    (osp_api.hip, merge_pipeline; OSP_PLAN_OVERLAP=0 plans in line).  Direct rows, hub rows and split rows in one product,
+    (osp_pipeline.h, merge_pipeline; OSP_PLAN_OVERLAP=0 plans in line).  Direct rows, hub rows and split rows in one product,
     resident and streamed, twice in a row on one context (the pool hands the first product's buffers to the second): the
     same bits as the oracle either way, and the info says how many plans ran beside a multiply."""
     from outerspace_amd import spgemm as S
@@ -1251,7 +1251,7 @@ def test_dense_long_rows_are_direct_rows(port, monkeypatch, _ctx_shared, dt):
 ])
 def test_dense_and_small_column_counts(port, monkeypatch, _ctx_shared, scale, ef, preset, row_max, direct_max, cap):
     """Matrices with few columns (2^9 .. 2^13) whose long rows hold many products per column: the column ranges of such
-    rows are capped at the dense accumulators' width (osp_api.hip, bits_cap) and the rows are written by range directly
+    rows are capped at the dense accumulators' width (osp_pipeline.h, bits_cap) and the rows are written by range directly
     whatever their length (osp_split.h, `capped`).  Limits moved so that every combination of direct / split / stretch rows and
     of dense / sorted segments occurs at sizes the oracle forms in seconds; same bits as the oracle."""
     monkeypatch.setenv("OSP_SPLIT_ROW_MAX", row_max)

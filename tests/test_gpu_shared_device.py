@@ -72,7 +72,7 @@ print("OVERLAP_OK")
 @pytest.mark.parametrize("mode", ["OSP_POISON", "OSP_GUARD", "OSP_GATHER_MAX_RUNS"])
 def test_plan_overlap_under_poison_and_guard(mode, port):
     """The plan of panel p+1 runs on the context's second stream beside the multiply of panel p, and the buffer pool is not
-    stream-aware (osp_api.hip, Context::fork_window).  Products of many panels with the plans overlapped, in a process of
+    stream-aware (osp_context.h, Context::fork_window).  Products of many panels with the plans overlapped, in a process of
     their own with every pooled buffer poisoned on allocation (OSP_POISON: a read of memory nobody wrote gives the same
     wrong bits every time) or with guard zones around every buffer, checked when it is released (OSP_GUARD): bit-identical
     to the oracle, and the library's own check that nothing is released inside the fork window stays silent."""
