@@ -1165,27 +1165,47 @@ __global__ void short_rowfirst_kernel(const uint32_t *rowfirst, const uint32_t *
 // A gathered row may have a range that exceeds a tile (the hub columns: one column fed by more chunks than a tile holds
 // entries).  Such a segment goes to the paths for over-long segments -- dense accumulators, big in-place tiles, the global sort
 // -- which read RECORDS: this kernel writes the segment's records where they would have been written (its place in the second
-// buffer), from its run descriptors; everything else of the row stays virtual.  One workgroup per segment, a wave per slice.
+// buffer), from its run descriptors; everything else of the row stays virtual.  Jobs of kExpandJob products, a wave per slice
+// (a segment of a row of many chunks holds thousands of runs: the slice's first run is found with 64 probes a step).
+// jobs of over-long segment number t of the list: kExpandJob products each; segments of rows that are not gathered have none
+struct SegExpandJobs {
+    const uint32_t *seglist; const uint64_t *vrow_off; const uint32_t *vrun_off;
+    __device__ uint64_t operator()(uint64_t t) const {
+        const uint32_t v = seglist[t];
+        if (vrun_off[v] == kNoRuns) return 0ull;
+        return (vrow_off[v + 1] - vrow_off[v] + kExpandJob - 1) / kExpandJob;
+    }
+};
 template <class T>
 __global__ __launch_bounds__(kExpandThreads) void expand_segments_kernel(
-    const uint32_t *__restrict__ seglist, uint32_t nseg, const uint64_t *__restrict__ vrow_off, const uint32_t *__restrict__ vrun_off,
-    const uint32_t *__restrict__ vrun_end, const RunDesc<T> *__restrict__ runs, const uint32_t *__restrict__ b_colidx, const T *__restrict__ b_vals,
-    Part<T> *__restrict__ qstage) {
-    if (blockIdx.x >= nseg) return;
-    const uint32_t v = seglist[blockIdx.x];
-    const uint32_t r0 = vrun_off[v];
-    if (r0 == kNoRuns) return;   // not a gathered row: its records are there
-    const uint32_t R = vrun_end[v] - r0;
-    const uint64_t s = vrow_off[v], n = vrow_off[v + 1] - s;
-    const uint32_t s32 = (uint32_t)s;   // (run positions are 32 bits wide, modulo)
+    const uint32_t *__restrict__ seglist, uint32_t nseg, const uint64_t *__restrict__ jobbase, const uint64_t *__restrict__ vrow_off,
+    const uint32_t *__restrict__ vrun_off, const uint32_t *__restrict__ vrun_end, const RunDesc<T> *__restrict__ runs,
+    const uint32_t *__restrict__ b_colidx, const T *__restrict__ b_vals, Part<T> *__restrict__ qstage) {
     const unsigned lane = lane_id(), w = threadIdx.x >> 6;
-    constexpr uint32_t per = 2048, NW = kExpandThreads / kWave, kUnroll = 4;
-    const RunDesc<T> *__restrict__ rd = runs + r0;
-    for (uint64_t p0 = (uint64_t)w * per; p0 < n; p0 += (uint64_t)NW * per) {
+    constexpr uint32_t NW = kExpandThreads / kWave, per = kExpandJob / NW, kUnroll = 4;
+    const uint64_t njobs = jobbase[nseg];
+    // (a fixed grid strides over the jobs: the host knows a bound of their number only -- every long row's products)
+    for (uint64_t job = blockIdx.x; job < njobs; job += gridDim.x) {
+        const uint32_t t = (uint32_t)(upper_bound_dev(jobbase, 0, (uint64_t)nseg + 1, job) - 1);
+        const uint32_t v = seglist[t];
+        const uint32_t r0 = vrun_off[v], R = vrun_end[v] - r0;
+        const uint64_t s = vrow_off[v], n = vrow_off[v + 1] - s;
+        const uint32_t s32 = (uint32_t)s;   // (run positions are 32 bits wide, modulo)
+        const RunDesc<T> *__restrict__ rd = runs + r0;
+        const uint64_t p0 = (job - jobbase[t]) * kExpandJob + (uint64_t)w * per;   // the wave's slice of the segment
+        if (p0 >= n) continue;
         const uint64_t p1 = min(p0 + per, n);
-        // last run that starts at or before p0
-        uint32_t lo = 0, hi = R;
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)(rd[mid].dst - s32) <= p0) lo = mid; else hi = mid; }
+        // last run that starts at or before p0: 64 probes a step (a segment of a hub row holds tens of thousands of runs)
+        uint32_t lo = 0, hi = R;   // the answer is in [lo, hi)
+        while (hi - lo > 1) {
+            const uint32_t span = hi - lo, step = (span + kWave - 1) / kWave;
+            const uint32_t q = lo + lane * step;                         // probes lo, lo + step, ... (those below hi count)
+            const bool le = q < hi && (uint64_t)(rd[q].dst - s32) <= p0;  // monotone: a prefix of the lanes
+            const uint32_t c = (uint32_t)__popcll(__ballot(le));          // >= 1: the run at lo starts at or before p0
+            const uint32_t nlo = lo + (c - 1) * step;
+            hi = min(hi, nlo + step);
+            lo = nlo;
+        }
         for (uint32_t c = lo; c < R; c += kWave) {
             const uint32_t cq = c + lane;
             const bool cv = cq < R;
@@ -1440,8 +1460,11 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                 const RunDesc<T> *__restrict__ gruns = dd.lvl ? ga.runs : ga.runs0;
                 const u32x2 ds2 = *reinterpret_cast<const u32x2 *>(&gruns[tid < dd.rcnt ? dd.rbeg + tid : dd.rbeg]);
+                const u32x2 ds3 = *reinterpret_cast<const u32x2 *>(&gruns[tid + NT < dd.rcnt ? dd.rbeg + tid + NT : dd.rbeg]);   // (rows of many short chunks: 250-400 runs per tile)
                 lrec[0].w[0] = ds2.x;
                 lrec[0].w[1] = ds2.y;
+                lrec[1].w[0] = ds3.x;
+                lrec[1].w[1] = ds3.y;
                 return;
             }
         }
@@ -1539,7 +1562,8 @@ __global__ __launch_bounds__(NT, (merge_waves_per_simd<T, NT, CAP, MAXWG, ABL>()
                 const RunDesc<T> *__restrict__ gruns = d.lvl ? ga.runs : ga.runs0;
                 for (uint32_t x = tid; x < R; x += NT) {
                     uint32_t dst = lrec[0].w[0], src = lrec[0].w[1];
-                    if (x != tid) { const RunDesc<T> rd = gruns[d.rbeg + x]; dst = rd.dst; src = rd.src; }
+                    if (x == tid + NT) { dst = lrec[1].w[0]; src = lrec[1].w[1]; }
+                    else if (x != tid) { const RunDesc<T> rd = gruns[d.rbeg + x]; dst = rd.dst; src = rd.src; }
                     const uint32_t st = dst - tile0;
                     gsrc[x] = src - st;
                     atomicOr(&sm.gbits[st >> 5], 1u << (st & 31u));

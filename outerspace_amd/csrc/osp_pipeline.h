@@ -466,9 +466,14 @@ static void merge_panel(Context *ctx, Result *res, PhaseTimer &tm, const MergeIO
             seg_nnz = sc.get<uint32_t>(nvirt + 1);
             lv.heavy_nnz[1] = seg_nnz;
             // over-long segments of gathered rows: their records, from their runs (the paths below read records)
-            if (pl.ga.runs)
-                expand_segments_kernel<T><<<nseg_long, kExpandThreads, 0, s>>>(p1.long_rows, nseg_long, vrow_off, pl.vrun_off, pl.vrun_end, pl.ga.runs,
-                                                                              pl.ga.b_colidx, pl.ga.b_vals, qstage);
+            if (pl.ga.runs) {
+                uint64_t *xsjob = sc.get<uint64_t>((uint64_t)nseg_long + 1);
+                uint64_t *xsjob_tmp = sc.get<uint64_t>(scan_scratch_entries((uint64_t)nseg_long + 1));
+                device_exclusive_scan<SegExpandJobs, uint64_t>(SegExpandJobs{p1.long_rows, vrow_off, pl.vrun_off}, nseg_long, xsjob, xsjob_tmp, s);
+                const uint64_t job_bound = nh / kExpandJob + nseg_long;
+                expand_segments_kernel<T><<<(unsigned)std::min<uint64_t>(job_bound, (uint64_t)ctx->cus * 8), kExpandThreads, 0, s>>>(
+                    p1.long_rows, nseg_long, xsjob, vrow_off, pl.vrun_off, pl.vrun_end, pl.ga.runs, pl.ga.b_colidx, pl.ga.b_vals, qstage);
+            }
             // first those whose column range is narrow (hub rows): one dense accumulator per column, no sort at all
             // (debugging aid: OSP_DENSE_SEG=0 leaves them to the two paths below)
             const uint32_t *rest_list = p1.long_rows;
