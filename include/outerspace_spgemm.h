@@ -9,7 +9,8 @@
  *   CSRMatrix{pos,data{idx,val}}            common.h:10-16,39-47  SoA arrays (ptr/idx/val); the reference's own AoS
  *                                                                 layout is taken as it stands by osp_spgemm_csc_csr_aos
  *   std::vector<COOMatrix> cscMulcsr(csc, csr)
- *                                           SimSpGEMM.cpp:265-281  osp_spgemm_csc_csr (multiply)
+ *                                           SimSpGEMM.cpp:265-281  osp_spgemm_csc_csr (multiply: inside the merge kernel for the rows
+ *                                                                 a plan covers, multiply_kernel / expand_rows_kernel for the rest)
  *   COOMatrix deduplicateCOO(coo)           SimSpGEMM.cpp:519-535  osp_spgemm_csc_csr (merge)
  *   mulflops_ref                            SimSpGEMM.cpp:884-891  osp_result_info.partials
  *   COOMatrix readcoo(istream&, NRow, NCol, sym)
@@ -41,8 +42,11 @@
 extern "C" {
 #endif
 
-#define OSP_VERSION 4   /* round of the build: 3 = osp_multi_*, osp_csr_bias_relu, osp_result_coo_rows, direct-row counters;
-                            4 = per-destination exchange streams (osp_multi_rank_info_t grew) */
+#define OSP_VERSION 5   /* round of the build: 3 = osp_multi_*, osp_csr_bias_relu, osp_result_coo_rows, direct-row counters;
+                            4 = per-destination exchange streams (osp_multi_rank_info_t grew);
+                            5 = osp_result_info_t grew (gathered_*, expand_*): since this version the two reference functions
+                                of osp_spgemm_csc_csr are ONE kernel for most rows -- the merge forms the partial products
+                                cscMulcsr would stage (same products, same order, same bits) */
 
 typedef enum osp_status {
     OSP_OK = 0,
