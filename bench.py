@@ -458,6 +458,53 @@ def cpu_baseline(ctx, csc, csr, n, target_partials, np_dtype, ptrs, full=False):
     return out, par
 
 
+def cpu_baseline_all_cores(csc, csr, n, np_dtype, threads, partials_each=4e7):
+    """BASELINE.md section 2's optional all-core line, labelled separately: the reference is single-threaded by construction, but
+    the outer product is k-separable -- `threads` host threads run the reference on `threads` disjoint k-slabs of about
+    `partials_each` partial products at the same time (ctypes releases the GIL; the slabs' results are not merged with each
+    other).  Aggregate output nnz/s over the wall time of the slowest."""
+    import threading
+    import torch
+    from oracle import oracle  # baseline only
+    if not oracle.have_ref():
+        return None
+    colptr, rowidx, avals = csc
+    rowptr, colidx, bvals = csr
+    cum = torch.cumsum((colptr[1:] - colptr[:-1]) * (rowptr[1:] - rowptr[:-1]), 0)
+    total = int(cum[-1])
+    # slabs from the middle of the k range on (the first columns are the hub columns: one of them alone is 1e8 products)
+    start = int(cum[n // 3])
+    marks = torch.tensor([min(start + int(partials_each) * i, total) for i in range(threads + 1)], device=cum.device)
+    ks = (torch.searchsorted(cum, marks) + 1).clamp_(max=n).tolist()
+    slabs = []
+    for k0, k1 in zip(ks[:-1], ks[1:]):
+        if k1 <= k0:
+            continue
+        a0, a1, b0, b1 = int(colptr[k0]), int(colptr[k1]), int(rowptr[k0]), int(rowptr[k1])
+        slabs.append(((colptr[k0:k1 + 1] - a0).cpu().numpy(), rowidx[a0:a1].cpu().numpy().view(np.uint32), avals[a0:a1].cpu().numpy().astype(np_dtype),
+                      (rowptr[k0:k1 + 1] - b0).cpu().numpy(), colidx[b0:b1].cpu().numpy().view(np.uint32), bvals[b0:b1].cpu().numpy().astype(np_dtype), k1 - k0))
+    res = [None] * len(slabs)
+
+    def work(i):
+        ac, ai, av, bc, bi, bv, K = slabs[i]
+        r = oracle.ref(np_dtype).spgemm_csx(K, ac, ai, av, bc, bi, bv, timing_only=True)
+        res[i] = (int(r["nnzc"]), int(r["partials"]))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(slabs))]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    secs = time.perf_counter() - t0
+    if any(r is None for r in res):
+        return None
+    nnz, P = sum(r[0] for r in res), sum(r[1] for r in res)
+    return {"value": nnz / secs, "unit": "nnz/s", "cores": len(slabs), "kind": "reference",
+            "sample": f"{len(slabs)} disjoint k-slabs of the same matrix at once, one host thread each ({P} partial products -> {nnz} nnz in {secs:.2f} s; "
+                      f"the reference is single-threaded: this is the k-separable outer product run side by side, the slabs' results not merged); "
+                      f"host has {os.cpu_count()} cores", "partials_per_s": P / secs, "seconds": secs}
+
+
 def row_slab_parity(ctx, csc, csr, n, target_partials, np_dtype, ptrs, device):
     """Parity of the WHOLE product on a row slab: the product is computed once more and kept; output rows [0, r1) -- about
     `target_partials` partial products over ALL k, the heaviest rows of an R-MAT matrix (the hub row, planned long rows, short
@@ -968,6 +1015,14 @@ def main():
             if out["slab_parity"]["status"] != "ok":
                 status = 3
             if not args.stream_output and args.workload == "rmat" and not args.a_mtx:
+                try:
+                    allc = cpu_baseline_all_cores(csc, csr, n, np_dtype, min(16, os.cpu_count() or 1))
+                except Exception as e:   # (an optional line: never at the price of the run)
+                    allc = {"error": repr(e)}
+                if allc:
+                    out["cpu_baseline_all_cores"] = allc
+                    if "value" in allc:
+                        note(f"CPU reference on {allc['cores']} threads side by side: {allc['value'] / 1e6:.1f} M nnz/s")
                 out["row_slab_parity"] = row_slab_parity(ctx, csc, csr, n, 5e7, np_dtype, ptrs, device)
                 note(f"row slab parity: {out['row_slab_parity']['status']}")
                 if out["row_slab_parity"]["status"] != "ok":
