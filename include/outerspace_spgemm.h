@@ -126,8 +126,10 @@ typedef struct osp_result_info {
     float ms_hub_plan_kernel;   /* the two hub_plan_kernel launches, the scans between them and the read-back, per panel with hub rows */
     uint32_t hub_plan_launches; /* panels with hub rows */
     uint64_t output_slack_bytes;/* since version 4: bytes of the result's colidx / vals allocations beyond nnz_c entries (they are
-                                   sized by the bound sum_i min(U_i, N) before the merge; copied to exact size only when the
-                                   slack exceeds a tenth of the device's memory -- 0 after such a copy) */
+                                   sized by the bound sum_i min(U_i, N) before the merge; copied to exact size only when BOTH hold:
+                                   the exact-size allocation would be under 70 % of the bound-sized one, and the slack exceeds a
+                                   tenth of the device's memory (per result: several live results each keep theirs) -- 0 after
+                                   such a copy) */
     uint64_t plans_overlapped;  /* since version 4: panels whose plan ran on the context's second stream, beside the multiply of the
                                    panel before (products of several panels; the phase and kernel times of the two then overlap) */
     uint64_t gathered_rows;     /* since version 5: direct rows that were never written: the merge kernel formed their partial
