@@ -412,11 +412,28 @@ static void copy_d2h(void *dst, const void *src, size_t bytes, hipStream_t s) {
 struct ZeroRegions {
     uint32_t *p[4];
     uint64_t words[4];
+    uint32_t val[4];   // the word every element of the region is set to (zero_async: 0; fill_async: e.g. 0xffffffff)
 };
 __global__ void zero_regions_kernel(const ZeroRegions z) {
 #pragma unroll
     for (int r = 0; r < 4; r++)
-        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < z.words[r]; i += (uint64_t)gridDim.x * blockDim.x) z.p[r][i] = 0u;
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < z.words[r]; i += (uint64_t)gridDim.x * blockDim.x) z.p[r][i] = z.val[r];
+}
+struct FillRegion { void *p; size_t bytes; uint32_t word; };
+static void fill_async(hipStream_t s, std::initializer_list<FillRegion> regions) {   // (pointer, bytes: multiples of 4, the word)
+    ZeroRegions z{};
+    int n = 0;
+    uint64_t most = 0;
+    for (auto &r : regions) {
+        if (n == 4 || (r.bytes & 3) || ((uintptr_t)r.p & 3)) throw Error(OSP_ERR_ARG, "fill_async: at most four word-aligned regions");
+        z.p[n] = (uint32_t *)r.p;
+        z.words[n] = r.bytes / 4;
+        z.val[n] = r.word;
+        most = std::max<uint64_t>(most, z.words[n]);
+        n++;
+    }
+    if (most == 0) return;
+    zero_regions_kernel<<<(unsigned)std::min<uint64_t>((most + 255) / 256, 2048), 256, 0, s>>>(z);
 }
 static void zero_async(hipStream_t s, std::initializer_list<std::pair<void *, size_t>> regions) {   // (pointer, bytes: multiples of 4)
     ZeroRegions z{};

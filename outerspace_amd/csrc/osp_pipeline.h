@@ -277,12 +277,12 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
             runs = sc.get<RunDesc<T>>(std::max<uint64_t>(nrd, 1));
             pl.vrun_off = sc.get<uint32_t>(pl.nvirt + 1);
             pl.vrun_end = sc.get<uint32_t>(pl.nvirt + 1);
-            OSP_HIP(hipMemsetAsync(pl.vrun_off, 0xff, (pl.nvirt + 1) * sizeof(uint32_t), s));   // kNoRuns: segments of rows that are not gathered
             gp.rdbase = rdbase; gp.vrun_off = pl.vrun_off; gp.vrun_end = pl.vrun_end;
             gp.rowruns = sc.get<uint32_t>(nlong);
-            OSP_HIP(hipMemsetAsync(gp.rowruns, 0xff, (uint64_t)nlong * sizeof(uint32_t), s));
             pl.nwritten = gp.nwritten = sc.get<uint32_t>(1);
-            zero_async(s, {{pl.nwritten, sizeof(uint32_t)}});
+            // kNoRuns: segments / rows that are not gathered (ONE kernel: a hipMemsetAsync costs the host tens of microseconds)
+            fill_async(s, {{pl.vrun_off, (pl.nvirt + 1) * sizeof(uint32_t), kNoRuns}, {gp.rowruns, (uint64_t)nlong * sizeof(uint32_t), kNoRuns},
+                           {pl.nwritten, sizeof(uint32_t), 0u}});
             gp.over = !(getenv("OSP_GATHER_OVER") && atoi(getenv("OSP_GATHER_OVER")) == 0);
             gp.av_in_order = ds->av_in_order ? 1u : 0u;
             pl.may_write = !gp.over;
