@@ -307,8 +307,8 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
             double tot = 0;
             for (int k = 0; k < 6; k++) tot += (double)hp[k];
             fprintf(stderr, "[osp]   planner cycles: header %.1f %%, chunk descriptors %.1f %%, histogram pass %.1f %%, grouping %.1f %%, cell pass %.1f %%, "
-                            "prefixes + output %.1f %%\n", 100 * hp[0] / tot, 100 * hp[1] / tot, 100 * hp[2] / tot, 100 * hp[3] / tot, 100 * hp[4] / tot,
-                    100 * hp[5] / tot);
+                            "prefixes + output %.1f %%; %.0f cycles per row, %u rows\n", 100 * hp[0] / tot, 100 * hp[1] / tot, 100 * hp[2] / tot, 100 * hp[3] / tot,
+                    100 * hp[4] / tot, 100 * hp[5] / tot, tot / std::max(1u, nlong), nlong);
         }
 #endif
         res->info.direct_plan_launches++;
