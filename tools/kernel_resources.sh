@@ -5,4 +5,4 @@ cd "$(dirname "$0")/../outerspace_amd/csrc" || exit 1
 pat=${1:-merge_tiles}; shift
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -c osp_api.hip -o /dev/null -Rpass-analysis=kernel-resource-usage "$@" 2>&1 |
   awk -v pat="$pat" '/Function Name:/ { on = index($0, pat) > 0; if (on) { n = $0; sub(/.*Function Name: /, "", n); sub(/ \[-Rpass.*/, "", n); printf "%s\n", substr(n, 1, 90) } }
-       on && /(VGPRs:|VGPR Spill|SGPRs:|Occupancy|LDS Size)/ { l = $0; sub(/.*remark: +/, "", l); sub(/ \[-Rpass.*/, "", l); printf "    %s\n", l }'
+       on && /(VGPRs:|Spill:|TotalSGPRs:|Occupancy|LDS Size|ScratchSize)/ { l = $0; sub(/.*remark: +/, "", l); sub(/ \[-Rpass.*/, "", l); printf "    %s\n", l }'
