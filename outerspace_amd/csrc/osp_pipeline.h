@@ -293,6 +293,12 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
         if (!(runs && gp.over) || (hub_b && pl.nblocks)) ds->ensure_chunk_off(s);
         gp.mark_skipped = ds->chunk_off_ready ? 1u : 0u;
         tm.begin(PH_PLAN_K, s);
+        if (nlong <= 4u * ctx->cus)   // few rows: the launch lasts as long as its longest row (osp_split.h, kDirectCellsBig)
+            direct_plan_kernel<T, kDirectCellsBig><<<nlong, kDirectThreads, 0, s>>>(pl.p0.long_rows, nlong, pl.hmode, pl.hbits, nseg, pl.vbase, pl.hoff,
+                                                                                 pl.cellbase, row_off, colbits, kCap, ds->rowfirst, ds->off, ds->bs, ds->perm,
+                                                                                 ds->b_colidx, pl.vrow_off, pl.vcol0, pl.vcol1, pl.cells, ds->chunk_off, gp,
+                                                                                 (const T *)ds->a_vals, runs);
+        else
         direct_plan_kernel<T><<<nlong, kDirectThreads, 0, s>>>(pl.p0.long_rows, nlong, pl.hmode, pl.hbits, nseg, pl.vbase, pl.hoff, pl.cellbase, row_off,
                                                               colbits, kCap, ds->rowfirst, ds->off, ds->bs, ds->perm, ds->b_colidx, pl.vrow_off,
                                                               pl.vcol0, pl.vcol1, pl.cells, ds->chunk_off, gp, (const T *)ds->a_vals, runs);

@@ -687,8 +687,14 @@ __global__ void gather_stats_kernel(const uint32_t *rows, uint32_t nlong, const 
     nr = wave_reduce_sum<uint64_t>(nr); np = wave_reduce_sum<uint64_t>(np); nd = wave_reduce_sum<uint64_t>(nd);
     if (lane_id() == 0 && nr) { atomicAdd(&gstat[0], (unsigned long long)nr); atomicAdd(&gstat[1], (unsigned long long)np); atomicAdd(&gstat[2], (unsigned long long)nd); }
 }
-template <class V>
-__global__ __launch_bounds__(kDirectThreads, 8) void direct_plan_kernel(
+// CL: LDS words for the (chunk, range) cells of a block of chunks, twice.  A row of many short chunks and a dozen ranges (the web
+// graphs' long rows: 1 125 chunks, 12 ranges) takes its chunks 1024 / 12 = 85 at a time, every block a chain of dependent loads
+// and barriers: fine while thousands of rows hide each other's latencies, but a launch of a few hundred rows lasts as long
+// as its longest row (0.21 ms of a 1.8 ms product).  Such launches -- all rows resident at once even at two workgroups per CU
+// -- run the instantiation with eight times the cells (and the block's A values in an array of their own).
+constexpr int kDirectCellsBig = 8 * OSP_DIRECT_CELLS_LDS;
+template <class V, int CL = OSP_DIRECT_CELLS_LDS>
+__global__ __launch_bounds__(kDirectThreads, (CL > OSP_DIRECT_CELLS_LDS ? 2 : 8)) void direct_plan_kernel(
     const uint32_t *__restrict__ rows, uint32_t nlong, const uint8_t *__restrict__ hmode, const uint8_t *__restrict__ hbits,
     const uint32_t *__restrict__ nseg, const uint64_t *__restrict__ vbase, const uint64_t *__restrict__ hoff,
     const uint64_t *__restrict__ cellbase, const uint64_t *__restrict__ row_off, int colbits, uint32_t cap,
@@ -697,7 +703,9 @@ __global__ __launch_bounds__(kDirectThreads, 8) void direct_plan_kernel(
     uint32_t *__restrict__ vcol0, uint32_t *__restrict__ vcol1, uint32_t *__restrict__ cells, uint64_t *__restrict__ chunk_off,
     const GatherPlan gp, const V *__restrict__ a_vals, RunDesc<V> *__restrict__ runs) {
     constexpr int NT = kDirectThreads, NFINE = 1 << kDirectFineBits, CBL = kDirectChunkBlock, UNR = OSP_DIRECT_UNR;
-    constexpr int kCellsLds = OSP_DIRECT_CELLS_LDS;
+    constexpr int kCellsLds = CL;
+    constexpr bool kBigCells = CL > OSP_DIRECT_CELLS_LDS;
+    __shared__ V avs_own[kBigCells ? CBL : 1];
     __shared__ alignas(8) uint32_t hist[NFINE + 1];     // bin counts, then their exclusive prefix (gathered rows, step 3: the block's A values)
     __shared__ alignas(4) uint16_t nxt[NFINE];          // first bin of the range that follows a range starting at this bin (gathered rows, step 3: runs per range)
     __shared__ uint8_t lut[NFINE];
@@ -835,10 +843,10 @@ __global__ __launch_bounds__(kDirectThreads, 8) void direct_plan_kernel(
     __syncthreads();
     if (gathered) {
         // ---- 3g. run descriptors (see above) ----
-        constexpr uint32_t kAvMax = (uint32_t)((NFINE + 1) * sizeof(uint32_t) / (sizeof(V)));   // A values of a block of chunks: where the histogram was
+        constexpr uint32_t kAvMax = kBigCells ? (uint32_t)CBL : (uint32_t)((NFINE + 1) * sizeof(uint32_t) / (sizeof(V)));   // A values of a block of chunks: where the histogram was
         const uint32_t CB = max(1u, min(min((uint32_t)CBL, (uint32_t)kCellsLds / T), kAvMax));
         const bool multi = nc > CB;
-        V *avs = reinterpret_cast<V *>(hist);
+        V *avs = kBigCells ? avs_own : reinterpret_cast<V *>(hist);
         uint32_t *nzc = reinterpret_cast<uint32_t *>(nxt), *ncur = rbin0;   // runs of every range (then: their exclusive prefix); runs written so far
         static_assert(sizeof(nxt) >= (kDirectMaxRanges + 1) * sizeof(uint32_t), "runs per range: where the grouping's chain was");
         const uint32_t rowbase = (uint32_t)gp.rdbase[h];
