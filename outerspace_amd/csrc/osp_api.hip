@@ -750,6 +750,7 @@ int osp_context_free(osp_context_t c_, void *device_ptr) {
 int osp_context_destroy(osp_context_t c_) {
     Context *c = (Context *)c_;
     if (!c) return OSP_OK;
+    if (c->sibling) c->sibling->sibling = nullptr;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->trim();
@@ -1118,6 +1119,8 @@ int osp_multi_context_create(const int *devices, int ndev, osp_multi_context_t *
             const int st2 = osp_context_create(devices[g], &c2);   // the merge of what arrives: a stream and a pool of its own
             if (st2) { delete mc; return st2; }
             mc->mctx.back() = (Context *)c2;
+            mc->ctx.back()->sibling = mc->mctx.back();
+            mc->mctx.back()->sibling = mc->ctx.back();
             OSP_HIP(hipSetDevice(devices[g]));
             for (int h = 0; h < ndev; h++) {
                 if (h == g) continue;

@@ -42,6 +42,7 @@ struct Context {
     bool dense_atomic[2] = {true, true};  // [0] f32, [1] f64
     // pool misses (OSP_VERBOSE prints them per product): device allocations are slow, a product should not need any
     // once the pool is warm
+    Context *sibling = nullptr;   // the other context of the same rank and device (osp_multi.h), same host thread: its pooled blocks are freed before an allocation fails
     uint64_t malloc_calls = 0, malloc_bytes = 0;
     double malloc_ms = 0;
 
@@ -156,6 +157,16 @@ struct Context {
                 (void)hipFree(big->second);
                 pooled_bytes -= big->first;
                 free_list.erase(big);
+                e = hipMalloc(&p, b);
+            }
+            // ... then the sibling's (a rank of the multi-GPU path has two contexts on one device, used by one host thread: what the
+            // multiply's context has released is no use to anybody while the merge's context runs out of memory)
+            while (e != hipSuccess && sibling && !sibling->free_list.empty()) {
+                (void)hipGetLastError();
+                auto big = std::prev(sibling->free_list.end());
+                (void)hipFree(big->second);
+                sibling->pooled_bytes -= big->first;
+                sibling->free_list.erase(big);
                 e = hipMalloc(&p, b);
             }
             if (e != hipSuccess) {

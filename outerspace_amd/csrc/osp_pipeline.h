@@ -733,7 +733,7 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     // buffer and its temporary output (each up to one panel): budget a third of it, with slack.
     size_t free_b = 0, total_b = 0;
     OSP_HIP(hipMemGetInfo(&free_b, &total_b));
-    free_b += ctx->pooled_bytes;
+    free_b += ctx->pooled_bytes + (ctx->sibling ? ctx->sibling->pooled_bytes : 0);   // (what alloc() can free before it fails)
     uint64_t cap = cap_cfg;
     // streaming: the panel's output buffer (at most one record per partial product) comes out of the same budget
     // (debugging aid: OSP_STAGE_FACTOR overrides the number of record sizes budgeted per staged partial product)
