@@ -209,7 +209,7 @@ static void plan_panel(Context *ctx, Result *res, PhaseTimer &tm, PanelPlan<T> &
     // costs.  Measured (round 4): Graph500 scale 22 streamed 3.48 -> 3.23 s, scale 20 387 -> 368 ms with them (stretch rows:
     // more than half of the products); R-MAT-22 "mild" (2 %) 236 -> 250 ms.  OSP_HUB_MIN_SHARE moves the threshold.
     // fine bins of the direct rows' planner: 2^direct_fine per kSplitTarget products (osp_split.h, split_params_kernel)
-    const int direct_fine = getenv("OSP_DIRECT_FINE") ? std::max(0, std::min(atoi(getenv("OSP_DIRECT_FINE")), 4)) : 2;
+    const int direct_fine = 2;   // (0 = the bins of round 3; measured in round 4, MEASUREMENTS 1.x: the ranges fill their tiles to 97 % instead of 92)
     const double hub_min_share = getenv("OSP_HUB_MIN_SHARE") ? atof(getenv("OSP_HUB_MIN_SHARE")) : 0.2;
     bool hub_decided = false;
     for (int attempt = 0; attempt < 3; attempt++) {
@@ -736,13 +736,12 @@ static void merge_pipeline(Context *ctx, Result *res, Producer<T> &prod, uint64_
     free_b += ctx->pooled_bytes + (ctx->sibling ? ctx->sibling->pooled_bytes : 0);   // (what alloc() can free before it fails)
     uint64_t cap = cap_cfg;
     // streaming: the panel's output buffer (at most one record per partial product) comes out of the same budget
-    // (debugging aid: OSP_STAGE_FACTOR overrides the number of record sizes budgeted per staged partial product)
     // what a staged partial product needs: its record in the staging buffer, for 9 of 10 another one in the second buffer,
     // and a few per cent for tile tables and the cells of the direct rows -- 2.0 record sizes; 2.6 budgets 30 % on top of
     // that (3.3 until round 3: R-MAT-22 mild ran as 4 panels, now 3: one panel's planning, launches and read-backs less)
     // (round 5, gathered rows: nothing is written for nine records of ten, but both buffers are still addressed by the rows'
     // positions -- allocated in full -- and the run table is sized by a bound: measured 2.25 record sizes per product; 2.5)
-    const double per_record = getenv("OSP_STAGE_FACTOR") ? atof(getenv("OSP_STAGE_FACTOR")) : (sink ? 3.7 : (ds && ds->gather) ? 2.5 : 2.6);
+    const double per_record = sink ? 3.7 : (ds && ds->gather) ? 2.5 : 2.6;
     if (cap == 0) cap = std::max<uint64_t>((uint64_t)(free_b * 0.85 / (per_record * E)), 1ull << 20);
     cap = std::min<uint64_t>(cap, 0xfffffff0ull);  // staging positions are u32
     if (getenv("OSP_VERBOSE"))
