@@ -1172,7 +1172,8 @@ def main():
             "headline_rule": ("value = the k-split north_star names: the library's own product (shard k_library) when its child process ran and "
                               "its whole-result check passed, else the same decomposition over torch.distributed (shard k); the row-sharded product "
                               "(no exchange) is under decompositions.rows.  DESIGN.md section 5's model of the k-split: the exchange ships every "
-                              "partial product once -- x0.4 of one GPU at N = 2, x1.7 at 4, x5-6 at 8; rows scale from N = 2"),
+                              "partial product once -- about 560 / 140 / 40-45 ms at N = 2 / 4 / 8 for this workload against 176 ms on one GPU, i.e. x0.3, x1.3, "
+                              "x4; the row-sharded product (every rank runs the one-GPU pipeline on its rows) scales from N = 2"),
         })
         if lib_ok:
             out.update({
