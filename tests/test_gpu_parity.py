@@ -964,7 +964,8 @@ def test_slab_and_shard_sweep(ctx, preset, scale):
         nr = r.info["row_end"] - r.info["row_begin"] if kw.get("row_shard") else n
         out = (_as_tensor(rp, nr + 1, "<i8", dev, torch.int64).clone(), _as_tensor(ci, r.nnz, "<i4", dev, torch.int32).clone(),
                _as_tensor(va, r.nnz, "<f8", dev, torch.float64).view(torch.int64).clone(), r.info["partials"], r.info["panels"])
-        r.close()
+        torch.cuda.synchronize()   # the copies run on torch's stream: done before the buffers go back to the library's pool
+        r.close()                  # (OSP_POISON=1 refills them at once, on the library's stream)
         return out
     done = 0
     for it in range(int(os.environ.get("OSP_SWEEP_ITERS", "40"))):
