@@ -353,7 +353,9 @@ int osp_result_info(osp_result_t r, osp_result_info_t *info);
 /* Copy the CSR out.  rowptr[M+1], colidx[nnz_c], vals[nnz_c]; any pointer may be NULL. */
 int osp_result_copy_csr(osp_result_t r, int64_t *rowptr, uint32_t *colidx, void *vals,
                         osp_memspace_t space);
-/* Borrow the device arrays (valid until osp_result_destroy). */
+/* Borrow the device arrays (valid until osp_result_destroy).  They go back to the context's buffer pool then, and the next
+ * product of the context may write to them at once, on the CONTEXT's stream: work the caller has queued on a stream of its
+ * own that still reads them (a copy, a reduction) must have completed before osp_result_destroy is called. */
 int osp_result_device_ptrs(osp_result_t r, const int64_t **rowptr, const uint32_t **colidx,
                            const void **vals);
 int osp_result_destroy(osp_result_t r);
