@@ -1000,8 +1000,10 @@ __global__ __launch_bounds__(256) void rank_order_selftest_kernel(uint32_t *bad)
     if (nbad) atomicAdd(bad, nbad);
 }
 
-// (Tickets: the persistent workgroups of merge_tiles_kernel take their tiles from ONE counter word, and that word is what
-// bounds the kernel today.  A word serves about 88 returning atomics per microsecond on MI355X whoever asks
+// (Tickets: the persistent workgroups of merge_tiles_kernel take their tiles from ONE counter word, and that word was what
+// bounded the kernel in rounds 3-4 (staged tiles: 77 per microsecond); since round 5 a tile also forms its partial products and the
+// kernel takes 73 per microsecond for what its workgroups compute -- but the word is the next ceiling: a tile more than a tenth
+// cheaper will not show before two tiles share a ticket.  A word serves about 88 returning atomics per microsecond on MI355X whoever asks
 // (/opt/skills/guides/MI355X_MICROARCH.md, price list, "dequeue"); the kernel hands out 68-76 tiles per microsecond, and
 // tools/bench_merge with the sort AND the look-back switched off still takes 2.19 ms for 174 763 tiles (80 per
 // microsecond) -- while the same kernel with tiles assigned statically (no ticket, no look-back) SORTS them in 1.79 ms, and
